@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Generates tests/golden/*.npz by running the REFERENCE ITSELF (/root/reference, imported in place;
+nothing of it is copied) on the bundled scene, and records how the oracle restatement compares
+(tests/golden/PIN_REPORT.json).  Run in the build container only:
+
+    python oracle/gen_golden.py
+
+cv2 / scikit-image / rasterio are not installed, so inert stub modules are put in sys.modules
+before the import; only reference functions that never touch them are executed:
+robust_normalize, calculate_*, perform_pca, prepare_level_1_features,
+unsupervised_kmeans_classification, supervised_classification_predict, predict_image.
+"""
+import json
+import os
+import pickle
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "rs-image-segmentation_amd"))
+
+
+def import_reference():
+    for name in ["cv2", "skimage", "skimage.feature", "rasterio", "rasterio.transform", "rasterio.crs",
+                 "affine"]:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage.feature"].graycomatrix = None
+    sys.modules["skimage.feature"].graycoprops = None
+    sys.modules["skimage.feature"].local_binary_pattern = None
+    sys.modules["rasterio.transform"].Affine = None
+    sys.modules["rasterio.transform"].from_origin = None
+    sys.modules["affine"].Affine = None
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, os.path.join(REF, "modules"))
+    sys.path.insert(0, REF)
+    import importlib
+    ref_idx = importlib.import_module("modules.features.indices")
+    ref_ext = importlib.import_module("modules.features.extract")
+    ref_sup = importlib.import_module("modules.supervised_classifiers")
+    return ref_idx, ref_ext, ref_sup
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    from threadpoolctl import threadpool_limits
+    from rsseg.tiff import read_tiff  # the product's own TIFF reader (I/O only)
+    ref_idx, ref_ext, ref_sup = import_reference()
+    # our `modules` mirror must not shadow the reference's in this process
+    assert ref_idx.__file__.startswith(REF), ref_idx.__file__
+    from oracle import ref_np as O
+    import joblib
+
+    os.makedirs(OUT, exist_ok=True)
+    report = {}
+
+    # ---------------- inputs: the bundled scene (data file of the reference) ----------------
+    dn = read_tiff(os.path.join(REF, "data/raw/AA.tif"))
+    assert dn.shape == (7, 600, 600) and dn.dtype == np.uint8
+    class_map = np.load(os.path.join(REF, "output/class_map.npy"))
+    coords, labels = pickle.load(open(os.path.join(REF, "data/samples.pkl"), "rb"))
+    roi = np.load(os.path.join(REF, "output/ROI/roi_mask.npy"))
+    np.savez_compressed(os.path.join(OUT, "scene_aa.npz"), dn=dn, class_map=class_map.astype(np.uint8),
+                        sample_coords=np.asarray(coords, np.int64), sample_labels=np.asarray(labels, np.int64),
+                        roi_mask=roi.astype(np.int16))
+    model = joblib.load(os.path.join(REF, "output/rf_samples_model.pkl"))
+    forest = O.flatten_forest(model)
+    np.savez_compressed(os.path.join(OUT, "rf_samples_model_flat.npz"), **forest)
+
+    bands = O.stage1_preprocess(dn)
+
+    # ---------------- crop fixtures: reference outputs on a 96x96 window ----------------
+    y0, x0, S = 250, 180, 96
+    crop = [np.ascontiguousarray(b[y0:y0 + S, x0:x0 + S]) for b in bands]
+    with threadpool_limits(limits=1):
+        g = {"bands": np.stack(crop)}
+        norm = [ref_idx.robust_normalize(b) for b in crop]
+        g["norm"] = np.stack(norm)
+        blue, green, red, nir, swir1 = norm[:5]
+        idx = {
+            "ndvi": ref_idx.calculate_ndvi(nir, red), "evi": ref_idx.calculate_evi(nir, red, blue),
+            "msavi": ref_idx.calculate_msavi(nir, red), "ndwi": ref_idx.calculate_ndwi(green, nir),
+            "mndwi": ref_idx.calculate_mndwi(green, swir1), "ndbi": ref_idx.calculate_ndbi(swir1, nir),
+            "bsi": ref_idx.calculate_bsi(blue, red, nir, swir1)}
+        for k, v in idx.items():
+            g["idx_" + k] = v
+        pca7, ratio7, m7 = ref_idx.perform_pca(norm, use_robust_scaling=True)
+        pca3, ratio3, m3 = ref_idx.perform_pca(norm, n_components=3, use_robust_scaling=True)
+        g["pca7"] = np.stack(pca7); g["pca7_ratio"] = ratio7; g["pca7_components"] = m7.components_
+        g["pca7_mean"] = m7.mean_
+        g["pca3"] = np.stack(pca3); g["pca3_ratio"] = ratio3
+        fd = dict(idx); fd["pca_result"] = pca7
+        g["level1"] = ref_idx.prepare_level_1_features(fd)
+        # KMeans through the reference function, explicit keys (7 indices, float32)
+        keys = ["ndvi", "evi", "msavi", "ndwi", "mndwi", "ndbi", "bsi"]
+        kd = dict(idx); kd["height"], kd["width"] = S, S
+        for k in (6, 7, 8):
+            g[f"kmeans_idx7_k{k}"] = ref_ext.unsupervised_kmeans_classification(kd, k, keys).astype(np.int32)
+        # KMeans on a 19-column float64 stack: the cv2/skimage columns come from the oracle
+        _, hier = O.run_feature_extraction_stage(crop, glcm_window=21, glcm_step=21)
+        g["stack19"] = hier["all"]
+        kd2 = {"hierarchical_all": hier["all"], "height": S, "width": S}
+        for k in (6, 8):
+            g[f"kmeans_stack19_k{k}"] = ref_ext.unsupervised_kmeans_classification(
+                kd2, k, ["hierarchical_all"]).astype(np.int32)
+        # NaN handling of the KMeans entry point
+        kd3 = dict(kd); nd = idx["ndvi"].copy(); nd[5, 7] = np.nan; nd[40, :3] = np.nan; kd3["ndvi"] = nd
+        g["kmeans_idx7_nan_k6"] = ref_ext.unsupervised_kmeans_classification(kd3, 6, keys).astype(np.int32)
+        g["kmeans_idx7_nan_input"] = nd
+
+        # RF goldens: seeded random matrix with NaNs and exact-threshold values
+        rng = np.random.default_rng(20250613)
+        Xrf = rng.uniform(-1.0, 1.0, (4096, 19)).astype(np.float64)
+        thr = forest["threshold"][forest["left"] != -1]
+        feat = forest["feature"][forest["left"] != -1]
+        for r in range(0, 600):
+            j = rng.integers(0, thr.size)
+            Xrf[r, feat[j]] = np.float32(thr[j]) if r % 2 == 0 else np.nextafter(np.float32(thr[j]), np.float32(9))
+        Xrf_nan = Xrf.copy()
+        Xrf_nan[rng.integers(0, 4096, 200), rng.integers(0, 19, 200)] = np.nan
+        g["rf_X"] = Xrf.astype(np.float32)
+        g["rf_pred_image"] = ref_sup.predict_image(model, Xrf.reshape(64, 64, 19)).astype(np.int64)
+        g["rf_X_nan"] = Xrf_nan.astype(np.float32)
+        # extract.py:710-712 replaces NaN by 0 before predict; sklearn's own NaN routing is exercised
+        # by calling the model the way predict_image does (no replacement):
+        g["rf_pred_nan_zeroed"] = ref_ext.supervised_classification_predict(
+            Xrf_nan.reshape(64, 64, 19), model).astype(np.int64)
+        g["rf_pred_nan_native"] = ref_sup.predict_image(model, Xrf_nan.reshape(64, 64, 19)).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "crop96.npz"), **g)
+
+    # ---------------- full-scene label goldens (config C1 shape) ----------------
+    with threadpool_limits(limits=1):
+        normF = [ref_idx.robust_normalize(b) for b in bands]
+        b_, g_, r_, n_, s_ = normF[:5]
+        idxF = {"ndvi": ref_idx.calculate_ndvi(n_, r_), "evi": ref_idx.calculate_evi(n_, r_, b_),
+                "msavi": ref_idx.calculate_msavi(n_, r_), "ndwi": ref_idx.calculate_ndwi(g_, n_),
+                "mndwi": ref_idx.calculate_mndwi(g_, s_), "ndbi": ref_idx.calculate_ndbi(s_, n_),
+                "bsi": ref_idx.calculate_bsi(b_, r_, n_, s_)}
+        kdF = dict(idxF); kdF["height"], kdF["width"] = 600, 600
+        full = {}
+        for k in (6, 8):
+            full[f"kmeans_idx7_k{k}"] = ref_ext.unsupervised_kmeans_classification(
+                kdF, k, ["ndvi", "evi", "msavi", "ndwi", "mndwi", "ndbi", "bsi"]).astype(np.uint8)
+        pcaF, ratioF, mF = ref_idx.perform_pca(normF, use_robust_scaling=True)
+        full["pca_ratio"] = ratioF
+        full["pca_components"] = mF.components_
+        full["pc0_sample"] = pcaF[0][::7, ::7].copy()
+        full["percentiles_2_98"] = np.array([[np.percentile(b, 2), np.percentile(b, 98)] for b in bands],
+                                            np.float32)
+    np.savez_compressed(os.path.join(OUT, "scene_aa_ref_outputs.npz"), **full)
+
+    # ---------------- pin report: oracle restatement vs reference ----------------
+    def eq(a, b):
+        return bool(np.array_equal(a, b, equal_nan=True))
+
+    o_norm = [O.robust_normalize(b) for b in crop]
+    report["robust_normalize_bitexact"] = all(eq(a, b) for a, b in zip(o_norm, norm))
+    ob, og, orr, on, osw = o_norm[:5]
+    o_idx = {"ndvi": O.calculate_ndvi(on, orr), "evi": O.calculate_evi(on, orr, ob),
+             "msavi": O.calculate_msavi(on, orr), "ndwi": O.calculate_ndwi(og, on),
+             "mndwi": O.calculate_mndwi(og, osw), "ndbi": O.calculate_ndbi(osw, on),
+             "bsi": O.calculate_bsi(ob, orr, on, osw)}
+    report["indices_bitexact"] = {k: eq(o_idx[k], idx[k]) for k in idx}
+    with threadpool_limits(limits=1):
+        op7, or7, om7 = O.perform_pca(o_norm)
+    report["pca7_max_abs_diff"] = float(max(np.max(np.abs(a - b)) for a, b in zip(op7, pca7)))
+    report["pca7_ratio_max_abs_diff"] = float(np.max(np.abs(or7 - ratio7)))
+    for k in (6, 7, 8):
+        lab, info = O.kmeans_fit_planes([o_idx[n] for n in keys], k)
+        refl = g[f"kmeans_idx7_k{k}"].reshape(-1)
+        report[f"kmeans_idx7_k{k}"] = dict(mismatch=int(np.sum(lab != refl)), n=int(lab.size),
+                                           n_iter=info["n_iter"])
+    for k in (6, 8):
+        lab, info = O.kmeans_fit_planes([hier["all"][:, :, i] for i in range(19)], k)
+        refl = g[f"kmeans_stack19_k{k}"].reshape(-1)
+        report[f"kmeans_stack19_k{k}"] = dict(mismatch=int(np.sum(lab != refl)), n=int(lab.size),
+                                              n_iter=info["n_iter"])
+    for k in (6, 8):
+        lab, info = O.kmeans_fit_planes([idxF[n] for n in keys], k)
+        refl = full[f"kmeans_idx7_k{k}"].reshape(-1)
+        report[f"kmeans_scene_idx7_k{k}"] = dict(mismatch=int(np.sum(lab != refl)), n=int(lab.size),
+                                                 n_iter=info["n_iter"])
+    rf_o = O.rf_predict_planes(forest, [g["rf_X"][:, i] for i in range(19)])
+    report["rf_mismatch"] = int(np.sum(rf_o != g["rf_pred_image"].reshape(-1)))
+    rf_n = O.rf_predict_planes(forest, [g["rf_X_nan"][:, i] for i in range(19)])
+    report["rf_nan_native_mismatch"] = int(np.sum(rf_n != g["rf_pred_nan_native"].reshape(-1)))
+    # end to end through the reference's committed class_map.npy (cv2/skimage stages included)
+    _, hierF = O.run_feature_extraction_stage(bands)
+    cm = O.predict_image(forest, hierF["all"])
+    report["class_map_agreement"] = float(np.mean(cm == class_map))
+    report["class_map_samples_ok"] = int(sum(cm[y, x] == l for (x, y), l in zip(coords, labels)))
+    report["class_map_samples_n"] = len(labels)
+    import sklearn
+    report["versions"] = dict(numpy=np.__version__, sklearn=sklearn.__version__)
+    with open(os.path.join(OUT, "PIN_REPORT.json"), "w") as f:
+        json.dump(report, f, indent=1, sort_keys=True)
+    print(json.dumps(report, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

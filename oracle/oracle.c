@@ -1,0 +1,208 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, gcc) of the loops on the hot path of
+ * beilsme/rs-image-segmentation that are too slow to restate in NumPy:
+ * KMeans (kmeans_impl.h), the GLCM texture windows and the random-forest walk.
+ * Nothing under rs-image-segmentation_amd/ may link, import or call this file; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Build:  make -C oracle      (gcc -O2 -ffp-contract=off; FMA only where written as fma())
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+#define MAXF 32
+#define MAXK 64
+#define FX_ONE 1099511627776.0          /* 2^40 */
+#define FX_INV (1.0 / 1099511627776.0)  /* 2^-40 */
+
+#define T float
+#define TSUF f32
+#define TEPS 1.1920928955078125e-07f
+#define TFMA(a, b, c) fmaf((a), (b), (c))
+#define TSQRT(x) sqrtf(x)
+#include "kmeans_impl.h"
+#undef T
+#undef TSUF
+#undef TEPS
+#undef TFMA
+#undef TSQRT
+
+#define T double
+#define TSUF f64
+#define TEPS 2.220446049250313e-16
+#define TFMA(a, b, c) fma((a), (b), (c))
+#define TSQRT(x) sqrt(x)
+#include "kmeans_impl.h"
+#undef T
+#undef TSUF
+#undef TEPS
+#undef TFMA
+#undef TSQRT
+
+/* ------------------------------------------------------------------------------------------
+ * GLCM texture windows.
+ * Reference: modules/features/indices.py:283-305 — per window
+ *   graycomatrix(window, [1], [0, pi/4, pi/2, 3pi/4], levels, symmetric=True, normed=True)
+ *   graycoprops(...).mean() for contrast, dissimilarity, homogeneity, energy, correlation.
+ * Third-party algorithm (scikit-image, un-vendored and unpinned in requirements.txt; restated
+ * from skimage/feature/texture.py + _texture.pyx::_glcm_loop as published for 0.19-0.25):
+ *   offset_row = round(sin(angle) * d), offset_col = round(cos(angle) * d)
+ *   -> (0,1), (1,1), (1,0), (1,-1) for the four angles; P += P^T; P /= P.sum().
+ *
+ * `q` is the already quantised uint8 image (values < levels).  Output maps are
+ * (oh, ow) float32, oh = (H - w) / step + 1.
+ *
+ * mode 0 ("literal"): builds the 4 normalised matrices and evaluates graycoprops' formulas on
+ *         them in float64, row-major.  This is the restatement of skimage.
+ * mode 1 ("pairs"):   the same five properties from exact integer pair statistics; this is the
+ *         bit-exact specification the HIP kernel implements ("GLCM numerics").
+ *         tests/test_oracle.py checks mode 0 == mode 1 to 1e-12.
+ * ------------------------------------------------------------------------------------------ */
+static const int GLCM_DR[4] = {0, 1, 1, 1};
+static const int GLCM_DC[4] = {1, 1, 0, -1};
+
+/* homogeneity weights 1/(1+d^2) as 2^-52 fixed point, d = |i-j| < 256 */
+static int64_t glcm_hq(int d) { return llrint(4503599627370496.0 / (1.0 + (double)d * (double)d)); }
+
+int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, int mode,
+                float *contrast, float *dissim, float *homog, float *energy, float *corr)
+{
+    if (levels < 2 || levels > 256 || win < 2 || win > H || win > W || step < 1) return -1;
+    const int oh = (H - win) / step + 1, ow = (W - win) / step + 1;
+    const int LL = levels * levels;
+    uint32_t *G = (uint32_t *)malloc(sizeof(uint32_t) * LL);
+    double *P = (double *)malloc(sizeof(double) * LL);
+    if (!G || !P) return -2;
+    for (int oi = 0; oi < oh; oi++) {
+        for (int oj = 0; oj < ow; oj++) {
+            const uint8_t *wp = q + (size_t)(oi * step) * W + (size_t)oj * step;
+            double pc[4], pd[4], ph[4], pe[4], pr[4];
+            for (int a = 0; a < 4; a++) {
+                const int dr = GLCM_DR[a], dc = GLCM_DC[a];
+                const int r0 = dr < 0 ? -dr : 0, r1 = dr > 0 ? win - dr : win;
+                const int c0 = dc < 0 ? -dc : 0, c1 = dc > 0 ? win - dc : win;
+                memset(G, 0, sizeof(uint32_t) * LL);
+                int64_t np = 0, S1 = 0, S2 = 0, Hq = 0, M1 = 0, M2 = 0, Mx = 0;
+                for (int r = r0; r < r1; r++)
+                    for (int c = c0; c < c1; c++) {
+                        int i = wp[(size_t)r * W + c], j = wp[(size_t)(r + dr) * W + (c + dc)];
+                        if (i >= levels || j >= levels) continue;
+                        G[i * levels + j]++;
+                        int d = i > j ? i - j : j - i;
+                        np++; S1 += d; S2 += d * d; Hq += glcm_hq(d);
+                        M1 += i + j; M2 += i * i + j * j; Mx += 2 * i * j;
+                    }
+                if (mode == 0) {
+                    double total = 0.0;
+                    for (int i = 0; i < levels; i++)
+                        for (int j = 0; j < levels; j++) {
+                            P[i * levels + j] = (double)(G[i * levels + j] + G[j * levels + i]);
+                            total += P[i * levels + j];
+                        }
+                    if (total == 0.0) total = 1.0;
+                    for (int t = 0; t < LL; t++) P[t] /= total;
+                    double con = 0, dis = 0, hom = 0, asm_ = 0, mi = 0, mj = 0;
+                    for (int i = 0; i < levels; i++)
+                        for (int j = 0; j < levels; j++) {
+                            double p = P[i * levels + j], dd = (double)(i - j);
+                            con += p * dd * dd;
+                            dis += p * fabs(dd);
+                            hom += p * (1.0 / (1.0 + dd * dd));
+                            asm_ += p * p;
+                            mi += i * p;
+                            mj += j * p;
+                        }
+                    double vi = 0, vj = 0, cov = 0;
+                    for (int i = 0; i < levels; i++)
+                        for (int j = 0; j < levels; j++) {
+                            double p = P[i * levels + j];
+                            vi += p * (i - mi) * (i - mi);
+                            vj += p * (j - mj) * (j - mj);
+                            cov += p * (i - mi) * (j - mj);
+                        }
+                    double si = sqrt(vi), sj = sqrt(vj);
+                    pc[a] = con; pd[a] = dis; ph[a] = hom; pe[a] = sqrt(asm_);
+                    pr[a] = (si < 1e-15 || sj < 1e-15) ? 1.0 : cov / (si * sj);
+                } else {
+                    int64_t A = 0;
+                    for (int i = 0; i < levels; i++)
+                        for (int j = 0; j < levels; j++) {
+                            int64_t g = (int64_t)G[i * levels + j] + (int64_t)G[j * levels + i];
+                            A += g * g;
+                        }
+                    const double npd = (double)np, tot = (double)(2 * np);
+                    if (np == 0) { pc[a] = pd[a] = ph[a] = pe[a] = 0.0; pr[a] = 1.0; continue; }
+                    pc[a] = (double)S2 / npd;
+                    pd[a] = (double)S1 / npd;
+                    ph[a] = ((double)Hq * (1.0 / 4503599627370496.0)) / npd;
+                    pe[a] = sqrt((double)A / (tot * tot));
+                    int64_t den = M2 * (2 * np) - M1 * M1, num = Mx * (2 * np) - M1 * M1;
+                    pr[a] = den == 0 ? 1.0 : (double)num / (double)den;
+                }
+            }
+            const size_t o = (size_t)oi * ow + oj;
+            contrast[o] = (float)((((pc[0] + pc[1]) + pc[2]) + pc[3]) / 4.0);
+            dissim[o] = (float)((((pd[0] + pd[1]) + pd[2]) + pd[3]) / 4.0);
+            homog[o] = (float)((((ph[0] + ph[1]) + ph[2]) + ph[3]) / 4.0);
+            energy[o] = (float)((((pe[0] + pe[1]) + pe[2]) + pe[3]) / 4.0);
+            corr[o] = (float)((((pr[0] + pr[1]) + pr[2]) + pr[3]) / 4.0);
+        }
+    }
+    free(G); free(P);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Random-forest inference.
+ * Reference: modules/supervised_classifiers.py:99-115 (predict_image) and
+ * modules/features/extract.py:690-719 -> RandomForestClassifier.predict:
+ *   X cast to float32                               sklearn/ensemble/_forest.py:640
+ *   per tree Tree._apply_dense                      sklearn/tree/_tree.pyx:955-996
+ *        NaN -> missing_go_to_left; else X[i,f] <= threshold (float32 promoted to float64)
+ *   proba_t = value[leaf, 0, :n_classes]            sklearn/tree/_classes.py:1058-1061
+ *   all_proba += proba_t in tree order (n_jobs=None) sklearn/ensemble/_forest.py:723-736, 948-959
+ *   all_proba /= n_trees; argmax (first max); classes_.take   sklearn/ensemble/_forest.py:903-906, 961-962
+ *
+ * Flattened forest: node arrays concatenated over trees, tree_off[t] = first node of tree t,
+ * children are tree-local indices (-1 = leaf), value is (n_nodes_total, n_classes) float64.
+ * X is feature-planar float32: planes[f][i].
+ * ------------------------------------------------------------------------------------------ */
+int oracle_rf_predict(const float *const *planes, int64_t N, int F, int n_trees, const int64_t *tree_off,
+                      const int32_t *left, const int32_t *right, const int32_t *feature,
+                      const double *threshold, const uint8_t *missing_left, const double *value,
+                      int n_classes, const int64_t *classes, int64_t *out)
+{
+    if (n_classes < 1 || n_classes > 64) return -1;
+    for (int64_t i = 0; i < N; i++) {
+        double acc[64];
+        for (int c = 0; c < n_classes; c++) acc[c] = 0.0;
+        for (int t = 0; t < n_trees; t++) {
+            const int64_t base = tree_off[t];
+            int32_t node = 0;
+            while (left[base + node] != -1) {
+                const int64_t g = base + node;
+                const float x = planes[feature[g]][i];
+                if (x != x) node = missing_left[g] ? left[g] : right[g];
+                else if ((double)x <= threshold[g]) node = left[g];
+                else node = right[g];
+            }
+            const double *v = value + (size_t)(base + node) * n_classes;
+            for (int c = 0; c < n_classes; c++) acc[c] += v[c];
+        }
+        int best = 0;
+        double bv = acc[0] / (double)n_trees;
+        for (int c = 1; c < n_classes; c++) {
+            double p = acc[c] / (double)n_trees;
+            if (p > bv) { bv = p; best = c; }
+        }
+        out[i] = classes[best];
+    }
+    return 0;
+}
