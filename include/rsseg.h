@@ -1,0 +1,182 @@
+/*
+ * rsseg.h — C ABI of librsseg_hip.so: MI355X (gfx950) kernels for the per-pixel
+ * feature-extraction -> clustering / classification path of beilsme/rs-image-segmentation.
+ *
+ * The reference has no FFI: its boundary for this path is a set of NumPy-in / NumPy-out Python
+ * functions.  Each entry point below names the reference function (file:line,
+ * relative to the reference repository) whose arithmetic it replaces; the Python mirror of those
+ * functions (rs-image-segmentation_amd/modules/...) binds this header through ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - Pointers named d_* are DEVICE addresses (e.g. torch tensor .data_ptr()); all others are host.
+ *   - Rasters are band/feature-PLANAR: one contiguous (H*W) plane per band, row-major.
+ *   - Every call is synchronous with respect to its results: it returns after the work it
+ *     enqueued on the context's stream has completed, unless stated otherwise.
+ *   - Return value: 0 = RSSEG_OK, negative = error (rsseg_last_error gives the text).  Never aborts.
+ *   - One caller thread per context (the reference is single-threaded).
+ *   - Multi-GPU: one context per process/GPU; a context given world > 1 calls the registered
+ *     all-reduce hook on small device buffers (RCCL through torch.distributed on the host side).
+ */
+#ifndef RSSEG_H
+#define RSSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSSEG_OK 0
+#define RSSEG_ERR_INVALID (-1)   /* bad argument (ValueError on the Python side) */
+#define RSSEG_ERR_HIP (-2)       /* HIP runtime error */
+#define RSSEG_ERR_NOMEM (-3)
+#define RSSEG_ERR_COMM (-4)      /* all-reduce hook failed */
+#define RSSEG_ERR_UNSUPPORTED (-5)
+
+#define RSSEG_F32 0
+#define RSSEG_F64 1
+#define RSSEG_I64 2
+
+#define RSSEG_SUM 0
+#define RSSEG_MIN 1
+#define RSSEG_MAX 2
+
+#define RSSEG_BORDER_REFLECT 0     /* cv2.BORDER_REFLECT      fedcba|abcdefgh|hgfedcb */
+#define RSSEG_BORDER_REFLECT101 1  /* cv2.BORDER_REFLECT_101  gfedcb|abcdefgh|gfedcba */
+
+#define RSSEG_MAX_FEATURES 32
+#define RSSEG_MAX_CLUSTERS 64
+#define RSSEG_MAX_RANKS 16
+
+typedef struct rsseg_ctx rsseg_ctx;
+
+/* All-reduce hook: reduce `count` elements of `dtype` (RSSEG_F32/F64/I64) with `op`
+ * (RSSEG_SUM/MIN/MAX) IN PLACE at byte offset `offset` of the communication buffer registered with
+ * rsseg_ctx_set_comm, across all ranks, ordered after the work already enqueued on the context's
+ * stream.  Returns 0 on success. */
+typedef int (*rsseg_allreduce_fn)(void *user, int64_t offset, int64_t count, int dtype, int op);
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * for a stream owned by the context. */
+int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out);
+void rsseg_ctx_destroy(rsseg_ctx *ctx);
+const char *rsseg_last_error(const rsseg_ctx *ctx);
+const char *rsseg_version(void);
+/* d_comm: device buffer of comm_bytes (>= 1 MiB) owned by the caller, visible to the hook. */
+int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn fn, void *user,
+                       void *d_comm, size_t comm_bytes);
+
+/* Per-kernel timing (HIP events on the context's stream, around each launch of the named
+ * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices",
+ * "select", "kpp", "box", "project", "gram", "forest", "resize", "stencil". */
+int rsseg_prof_enable(rsseg_ctx *ctx, int on);
+int rsseg_prof_reset(rsseg_ctx *ctx);
+int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+
+/* ---- K1: exact order statistics ------------------------------------------------------- */
+/* Replaces the partition inside np.percentile (modules/features/indices.py:38-39) and
+ * np.nanmedian / np.nanpercentile of RobustScaler (indices.py:230-231).
+ * For each r in ranks[0..nranks) (0-based positions in the ascending order of ALL n_global
+ * values, NaNs last) writes the value at that position to out_values.  n_nan_out receives the
+ * global NaN count.  The interpolation between neighbouring order statistics is done by the
+ * caller exactly as NumPy does (host arithmetic on two scalars). */
+int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, const int64_t *ranks,
+                          int nranks, float *out_values, int64_t *n_nan_out);
+
+/* ---- K2: percentile normalisation + spectral indices ------------------------------------ */
+/* robust_normalize (indices.py:25-48), elementwise part: clip to [lo,hi], (x-lo)/(hi-lo+1e-10)
+ * in float32.  d_out may alias d_x. */
+int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, float *d_out);
+
+/* Fused robust_normalize of the five bands the indices read + calculate_ndvi / evi / msavi /
+ * ndwi / mndwi / ndbi / bsi (indices.py:50-203; call order scripts/2_feature_extraction.py:63-73).
+ * d_bands[5] = raw blue, green, red, nir, swir1 planes; lohi[10] = (lo,hi) per band.
+ * d_out[7] = ndvi, evi, msavi, ndwi, mndwi, ndbi, bsi planes (any may be NULL = not wanted).
+ * d_norm[5] (optional, entries may be NULL) receive the normalised bands.
+ * If lohi == NULL the bands are taken as already normalised. */
+int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
+                               float *const *d_out, float *const *d_norm);
+
+/* ---- K3: PCA ------------------------------------------------------------------------------ */
+/* perform_pca (indices.py:205-246): RobustScaler transform x' = (float)((double)(x - center) /
+ * scale) applied on the fly, then mean / Gram accumulation (exact), covariance, symmetric
+ * eigen-decomposition, sign convention of sklearn's svd_flip, projection to n_components planes.
+ * d_bands[nb]: normalised band planes; center[nb] (float32 medians) and scale[nb] (float64 IQRs)
+ * come from K1 + host interpolation; pass center = NULL for no scaling.
+ * Outputs (host): components (n_components x nb, row-major, float32), explained_variance_ratio
+ * (n_components), mean (nb), explained_variance (n_components). d_out[n_components]: projected planes. */
+int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local,
+                                const float *center, const double *scale, int n_components,
+                                float *const *d_out, float *components, float *explained_variance_ratio,
+                                float *mean, float *explained_variance);
+
+/* ---- K4/K5: GLCM texture + bilinear upsample ------------------------------------------- */
+/* calculate_glcm_features (indices.py:248-318), window loop: d_q is the quantised uint8 plane
+ * ((band*(levels-1)).astype(uint8), :268), H x W.  Writes the five property maps
+ * (contrast, dissimilarity, homogeneity, energy, correlation), each ((H-win)/step+1) x
+ * ((W-win)/step+1) float32, mean over the 4 angles (0, 45, 90, 135 degrees, distance 1),
+ * symmetric + normalised co-occurrence. Any of d_props[i] may be NULL. */
+int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int levels, int win, int step,
+                  float *const *d_props);
+/* float32 plane in [0,1] -> uint8 by truncation of x*mult (indices.py:268, 415, 458). */
+int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, uint8_t *d_q);
+/* cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) for float32 (indices.py:308). */
+int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw);
+
+/* ---- K6/K7/K8: window operators ---------------------------------------------------------- */
+/* cv2.boxFilter(normalize=True) / cv2.blur for float32 (indices.py:770-771, 537, 541): k x k mean,
+ * float64 sums, border RSSEG_BORDER_*.  If square != 0 the input is squared (float32) first
+ * (blur(band*band), indices.py:541).  d_out64 (optional) receives the same values as float64
+ * (add_spatial_context writes into a float64 buffer, indices.py:765). */
+int rsseg_box_mean_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, int border, int square,
+                       float *d_out);
+/* std_dev_scale_k (indices.py:537-548): sqrt(max(blur(x*x) - blur(x)^2, 0)), REFLECT_101. */
+int rsseg_local_std_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
+/* cv2.morphologyEx(MORPH_GRADIENT, ones(k,k)) on uint8 (indices.py:422, 433); output uint8. */
+int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, uint8_t *d_out);
+/* sobel_mag (indices.py:477-480): 3x3 Sobel x/y of the uint8 plane as float32 / 255, magnitude,
+ * divided by (global max + 1e-10).  Two launches; the global max goes through the all-reduce hook. */
+int rsseg_sobel_mag_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out);
+
+/* ---- K9/K10: KMeans ------------------------------------------------------------------------ */
+typedef struct rsseg_kmeans_info {
+    int32_t n_iter;
+    int32_t relocated;            /* empty-cluster relocations performed */
+    double tol;                   /* tol * mean(var) actually used */
+    double scale[RSSEG_MAX_FEATURES];
+    double min[RSSEG_MAX_FEATURES];
+    double mean[RSSEG_MAX_FEATURES];
+    int64_t init_indices[RSSEG_MAX_CLUSTERS]; /* global pixel index of each k-means++ seed */
+    double ms_init;               /* wall milliseconds: scaler + k-means++ */
+    double ms_lloyd;              /* wall milliseconds: Lloyd iterations */
+} rsseg_kmeans_info;
+
+/* unsupervised_kmeans_classification (modules/features/extract.py:568-579): NaN->0, MinMaxScaler,
+ * KMeans(n_clusters, random_state=seed, n_init=1, init='k-means++', max_iter, tol).fit_predict.
+ * d_planes[F]: feature planes, all float32 (dtype RSSEG_F32) or all float64 (RSSEG_F64), n_local
+ * pixels each (this rank's stripe; ranks hold consecutive stripes in rank order).
+ * d_labels: int32[n_local], cluster ids 0..k-1.  centers (host, k*F doubles, scaled-and-centred
+ * space + mean added back, like cluster_centers_). */
+int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local,
+                             int k, uint32_t seed, int max_iter, double tol, int32_t *d_labels,
+                             double *centers, rsseg_kmeans_info *info);
+
+/* ---- K11: random-forest inference ---------------------------------------------------------- */
+/* Flattened sklearn forest (tree_ arrays concatenated; children are tree-local, -1 = leaf).
+ * value: (n_nodes_total x n_classes) float64 class fractions.  The forest is copied to the device
+ * and stays loaded in the context until the next load or destroy. */
+int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tree_off, const int32_t *left,
+                      const int32_t *right, const int32_t *feature, const double *threshold,
+                      const uint8_t *missing_go_left, const double *value, int n_classes,
+                      const int64_t *classes, int n_features);
+/* predict_image (modules/supervised_classifiers.py:99-115) / supervised_classification_predict
+ * (modules/features/extract.py:690-719): d_planes[F] float32 feature planes -> int64 class per pixel. */
+int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes, int F, int64_t n, int64_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSSEG_H */

@@ -1,0 +1,130 @@
+// Internal definitions shared by the gfx950 kernels of librsseg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rsseg.h"
+
+#define WAVE 64
+
+struct prof_entry {
+    double ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct forest_dev {
+    void *d_nodes = nullptr;    // packed 16-byte nodes
+    void *d_leafval = nullptr;  // double[n_nodes_total][n_classes]
+    void *d_treeoff = nullptr;  // int32[n_trees+1]
+    int n_trees = 0, n_classes = 0, n_features = 0;
+    int64_t n_nodes = 0;
+    int64_t classes[64];
+};
+
+struct rsseg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+    // communication
+    int rank = 0, world = 1;
+    rsseg_allreduce_fn allreduce = nullptr;
+    void *comm_user = nullptr;
+    char *d_comm = nullptr;
+    size_t comm_bytes = 0;
+    // workspace (device) and pinned host staging
+    char *d_ws = nullptr;
+    size_t ws_bytes = 0;
+    char *h_pin = nullptr;
+    size_t pin_bytes = 0;
+    // profiling
+    bool prof_on = false;
+    std::map<std::string, prof_entry> prof;
+    std::vector<hipEvent_t> event_pool;
+    forest_dev forest;
+};
+
+int rs_fail(rsseg_ctx *ctx, int code, const char *fmt, ...);
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return rs_fail(ctx, RSSEG_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,    \
+                           hipGetErrorString(e_));                                             \
+    } while (0)
+#define RSCHK(expr)                  \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != RSSEG_OK) return rc_; \
+    } while (0)
+
+// workspace: returns a device pointer valid until the next ws_reserve with a larger size
+int ws_reserve(rsseg_ctx *ctx, size_t bytes);
+int pin_reserve(rsseg_ctx *ctx, size_t bytes);
+// all-reduce of a small host array through the device comm buffer (no-op when world == 1)
+int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, int op);
+int stream_sync(rsseg_ctx *ctx);
+
+// scoped kernel timer (HIP events on ctx->stream) — active only when profiling is on
+struct prof_scope {
+    rsseg_ctx *ctx;
+    prof_entry *e = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    prof_scope(rsseg_ctx *c, const char *name);
+    ~prof_scope();
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename V>
+__device__ __forceinline__ V wave_sum(V v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// round-to-nearest-even fixed point, quantum 2^-40, exact for |x| < 2^11:
+// bits(fma(x, 2^40, 1.5*2^52)) - bits(1.5*2^52) == llrint(x * 2^40)
+#define FX_MAGIC 6755399441055744.0 /* 1.5 * 2^52 */
+__device__ __forceinline__ long long to_fixed40(double x)
+{
+    double d = fma(x, 1099511627776.0, FX_MAGIC);
+    return __double_as_longlong(d) - __double_as_longlong(FX_MAGIC);
+}
+#endif

@@ -1,0 +1,212 @@
+// Context, workspace, communication hook and per-kernel timers of librsseg_hip.so.
+#include <stdarg.h>
+
+#include "common.h"
+
+int rs_fail(rsseg_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+static thread_local char g_err[256] = "no context";
+
+extern "C" const char *rsseg_version(void) { return "rsseg-hip 0.1 (gfx950)"; }
+
+extern "C" const char *rsseg_last_error(const rsseg_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out)
+{
+    if (!out) return RSSEG_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device available (%s)", hipGetErrorString(e));
+        return RSSEG_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof(g_err), "device %d out of range (have %d)", device, ndev);
+        return RSSEG_ERR_INVALID;
+    }
+    rsseg_ctx *ctx = new rsseg_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        snprintf(g_err, sizeof(g_err), "hipSetDevice(%d) failed", device);
+        return RSSEG_ERR_HIP;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            snprintf(g_err, sizeof(g_err), "hipStreamCreate failed");
+            return RSSEG_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return RSSEG_OK;
+}
+
+extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof)
+        for (auto &p : kv.second.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->forest.d_nodes) (void)hipFree(ctx->forest.d_nodes);
+    if (ctx->forest.d_leafval) (void)hipFree(ctx->forest.d_leafval);
+    if (ctx->forest.d_treeoff) (void)hipFree(ctx->forest.d_treeoff);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn fn, void *user,
+                                  void *d_comm, size_t comm_bytes)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || world > RSSEG_MAX_RANKS)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "bad rank/world %d/%d", rank, world);
+    if (world > 1 && (!fn || !d_comm || comm_bytes < (1u << 20)))
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "world > 1 needs an all-reduce hook and a >= 1 MiB comm buffer");
+    ctx->rank = rank;
+    ctx->world = world;
+    ctx->allreduce = fn;
+    ctx->comm_user = user;
+    ctx->d_comm = (char *)d_comm;
+    ctx->comm_bytes = comm_bytes;
+    return RSSEG_OK;
+}
+
+int ws_reserve(rsseg_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return RSSEG_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_ws) HIPCHK(ctx, hipFree(ctx->d_ws));
+    ctx->d_ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+    hipError_t e = hipMalloc((void **)&ctx->d_ws, want);
+    if (e != hipSuccess) return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->ws_bytes = want;
+    return RSSEG_OK;
+}
+
+int pin_reserve(rsseg_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_bytes) return RSSEG_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pin) HIPCHK(ctx, hipHostFree(ctx->h_pin));
+    ctx->h_pin = nullptr;
+    ctx->pin_bytes = 0;
+    size_t want = (bytes + 65536) & ~((size_t)65535);
+    hipError_t e = hipHostMalloc((void **)&ctx->h_pin, want, hipHostMallocDefault);
+    if (e != hipSuccess) return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipHostMalloc(%zu) failed", want);
+    ctx->pin_bytes = want;
+    return RSSEG_OK;
+}
+
+int stream_sync(rsseg_ctx *ctx)
+{
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RSSEG_OK;
+}
+
+int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, int op)
+{
+    if (ctx->world <= 1) return RSSEG_OK;
+    const size_t esz = dtype == RSSEG_F32 ? 4 : 8;
+    const size_t bytes = esz * (size_t)count;
+    if (bytes > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "comm buffer too small (%zu > %zu)", bytes, ctx->comm_bytes);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
+    if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
+    HIPCHK(ctx, hipMemcpyAsync(host, ctx->d_comm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RSSEG_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------
+static hipEvent_t get_event(rsseg_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+prof_scope::prof_scope(rsseg_ctx *c, const char *name) : ctx(c)
+{
+    if (!c->prof_on) return;
+    e = &c->prof[name];
+    a = get_event(c);
+    b = get_event(c);
+    (void)hipEventRecord(a, c->stream);
+}
+
+prof_scope::~prof_scope()
+{
+    if (!e) return;
+    (void)hipEventRecord(b, ctx->stream);
+    e->pending.emplace_back(a, b);
+    e->launches++;
+}
+
+static void prof_drain(rsseg_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->prof) {
+        for (auto &p : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) kv.second.ms += ms;
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+extern "C" int rsseg_prof_enable(rsseg_ctx *ctx, int on)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    prof_drain(ctx);
+    ctx->prof_on = on != 0;
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_prof_reset(rsseg_ctx *ctx)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    prof_drain(ctx);
+    ctx->prof.clear();
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms, int64_t *launches)
+{
+    if (!ctx || !name) return RSSEG_ERR_INVALID;
+    prof_drain(ctx);
+    auto it = ctx->prof.find(name);
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return RSSEG_OK;
+}

@@ -1,0 +1,176 @@
+// K1 — exact order statistics of a float32 plane by 3-pass radix select (11 + 11 + 10 key bits).
+//
+// Replaces the introselect partition inside np.percentile (reference modules/features/indices.py:38-39)
+// and np.nanmedian / np.nanpercentile of sklearn's RobustScaler (indices.py:230-231).  All requested
+// ranks are resolved together: each pass reads the plane once (4 B/px, coalesced 16 B per lane),
+// builds LDS-private histograms per workgroup (one 2048-bin table per distinct key prefix still
+// alive) and flushes the non-zero bins to HBM with 64-bit atomics.  HBM-bound: 12 B/px for any
+// number of ranks <= RSSEG_MAX_RANKS.
+#include "common.h"
+
+#define SEL_BINS 2048
+#define SEL_THREADS 256
+
+__device__ __forceinline__ uint32_t f32_key(float x, bool &is_nan)
+{
+    uint32_t u = __float_as_uint(x);
+    is_nan = (u & 0x7fffffffu) > 0x7f800000u;
+    if (u == 0x80000000u) u = 0;  // -0.0 sorts with +0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// pass 0: shift 21, no prefix.  pass 1: prefix = key >> 21, bin = (key >> 10) & 2047.
+// pass 2: prefix = key >> 10, bin = key & 1023.
+template <int PASS>
+__global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__ x, int64_t n,
+                                                       const uint32_t *__restrict__ prefixes, int nprefix,
+                                                       unsigned long long *__restrict__ hist,
+                                                       unsigned long long *__restrict__ nan_count)
+{
+    extern __shared__ uint32_t lh[];  // nprefix * SEL_BINS
+    const int nb = (PASS == 0 ? 1 : nprefix) * SEL_BINS;
+    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) lh[i] = 0;
+    __shared__ uint32_t spre[RSSEG_MAX_RANKS];
+    if (PASS != 0 && threadIdx.x < nprefix) spre[threadIdx.x] = prefixes[threadIdx.x];
+    __syncthreads();
+    uint32_t my_nan = 0;
+    const int64_t n4 = n >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    auto handle = [&](float v) {
+        bool isn;
+        uint32_t k = f32_key(v, isn);
+        if (isn) {
+            my_nan++;
+            return;
+        }
+        if (PASS == 0) {
+            atomicAdd(&lh[k >> 21], 1u);
+        } else {
+            const uint32_t p = PASS == 1 ? (k >> 21) : (k >> 10);
+            const uint32_t b = PASS == 1 ? ((k >> 10) & 2047u) : (k & 1023u);
+            for (int j = 0; j < nprefix; j++)
+                if (spre[j] == p) atomicAdd(&lh[j * SEL_BINS + b], 1u);
+        }
+    };
+    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SEL_THREADS) {
+        float4 v = x4[i];
+        handle(v.x); handle(v.y); handle(v.z); handle(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) handle(x[(n4 << 2) + threadIdx.x]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) {
+        uint32_t c = lh[i];
+        if (c) atomicAdd(&hist[i], (unsigned long long)c);
+    }
+    if (PASS == 0) {
+        uint32_t t = wave_sum(my_nan);
+        if (lane_id() == 0 && t) atomicAdd(nan_count, (unsigned long long)t);
+    }
+}
+
+static float key_to_f32(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, const int64_t *ranks,
+                                     int nranks, float *out_values, int64_t *n_nan_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || n_local < 0 || !ranks || !out_values || nranks < 1 || nranks > RSSEG_MAX_RANKS)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: bad arguments (n=%lld nranks=%d)", (long long)n_local, nranks);
+    if (((uintptr_t)d_x & 15) != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: plane must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t hist_elems = (size_t)RSSEG_MAX_RANKS * SEL_BINS + 8;
+    const size_t hist_bytes = hist_elems * sizeof(unsigned long long);
+    RSCHK(ws_reserve(ctx, hist_bytes + 256));
+    RSCHK(pin_reserve(ctx, hist_bytes));
+    unsigned long long *d_hist = (unsigned long long *)ctx->d_ws;
+    unsigned long long *d_nan = d_hist + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
+    uint32_t *d_pre = (uint32_t *)(ctx->d_ws + hist_bytes);
+    long long *h_hist = (long long *)ctx->h_pin;
+
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RSSEG_MAX_RANKS * SEL_BINS * 4));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RSSEG_MAX_RANKS * SEL_BINS * 4));
+        attr_done = true;
+    }
+    int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, SEL_THREADS)));
+    int64_t rem[RSSEG_MAX_RANKS];
+    uint32_t prefix[RSSEG_MAX_RANKS];
+    bool is_nan_rank[RSSEG_MAX_RANKS];
+    int64_t n_global = 0, n_nan = 0;
+
+    for (int pass = 0; pass < 3; pass++) {
+        // distinct prefixes alive in this pass
+        uint32_t dp[RSSEG_MAX_RANKS];
+        int ndp = 0, slot[RSSEG_MAX_RANKS];
+        if (pass == 0) {
+            ndp = 1;
+            for (int r = 0; r < nranks; r++) slot[r] = 0;
+        } else {
+            for (int r = 0; r < nranks; r++) {
+                slot[r] = -1;
+                if (is_nan_rank[r]) continue;
+                for (int j = 0; j < ndp; j++)
+                    if (dp[j] == prefix[r]) slot[r] = j;
+                if (slot[r] < 0) {
+                    dp[ndp] = prefix[r];
+                    slot[r] = ndp++;
+                }
+            }
+            if (ndp == 0) break;
+            HIPCHK(ctx, hipMemcpyAsync(d_pre, dp, sizeof(uint32_t) * ndp, hipMemcpyHostToDevice, ctx->stream));
+        }
+        const size_t used = ((size_t)ndp * SEL_BINS) * sizeof(unsigned long long);
+        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_bytes, ctx->stream));
+        {
+            prof_scope ps(ctx, "select");
+            const size_t lds = (size_t)ndp * SEL_BINS * sizeof(uint32_t);
+            if (pass == 0)
+                hipLaunchKernelGGL(k1_hist<0>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+            else if (pass == 1)
+                hipLaunchKernelGGL(k1_hist<1>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+            else
+                hipLaunchKernelGGL(k1_hist<2>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, pass == 0 ? hist_bytes : used, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (pass == 0) {
+            RSCHK(comm_allreduce_host(ctx, h_hist, (int64_t)hist_elems, RSSEG_I64, RSSEG_SUM));
+            n_nan = h_hist[(size_t)RSSEG_MAX_RANKS * SEL_BINS];
+            n_global = n_nan;
+            for (int b = 0; b < SEL_BINS; b++) n_global += h_hist[b];
+            for (int r = 0; r < nranks; r++) {
+                if (ranks[r] < 0 || ranks[r] >= n_global)
+                    return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: rank %lld outside [0,%lld)", (long long)ranks[r], (long long)n_global);
+                is_nan_rank[r] = ranks[r] >= n_global - n_nan;
+                rem[r] = ranks[r];
+            }
+        } else {
+            RSCHK(comm_allreduce_host(ctx, h_hist, (int64_t)ndp * SEL_BINS, RSSEG_I64, RSSEG_SUM));
+        }
+        const int nbins = pass == 2 ? 1024 : SEL_BINS;
+        for (int r = 0; r < nranks; r++) {
+            if (is_nan_rank[r]) continue;
+            const long long *h = h_hist + (size_t)slot[r] * SEL_BINS;
+            int64_t acc = 0;
+            int b = 0;
+            for (; b < nbins; b++) {
+                if (rem[r] < acc + h[b]) break;
+                acc += h[b];
+            }
+            if (b == nbins) return rs_fail(ctx, RSSEG_ERR_HIP, "order_stats: inconsistent histogram (pass %d)", pass);
+            rem[r] -= acc;
+            prefix[r] = pass == 0 ? (uint32_t)b : ((prefix[r] << (pass == 1 ? 11 : 10)) | (uint32_t)b);
+        }
+    }
+    for (int r = 0; r < nranks; r++) out_values[r] = is_nan_rank[r] ? __builtin_nanf("") : key_to_f32(prefix[r]);
+    if (n_nan_out) *n_nan_out = n_nan;
+    return RSSEG_OK;
+}

@@ -1,0 +1,205 @@
+// K2 — percentile normalisation + the seven spectral indices, fused, float32, bit-exact with the
+// NumPy expressions of the reference (modules/features/indices.py:42-46, 62-69, 86-93, 109-112,
+// 128-135, 150-156, 171-177, 194-201).  Band-planar input, 16 B per lane per band, grid-stride.
+// HBM-bound: reads 5 planes (20 B/px), writes up to 7 (+5 normalised) planes.
+// Compiled with -ffp-contract=off: every NumPy operation is one IEEE float32 operation here.
+#include "common.h"
+
+#define K2_THREADS 256
+
+__device__ __forceinline__ float norm1(float x, float lo, float hi, float den)
+{
+    // np.clip keeps NaN; (clipped - lo) / (hi - lo + 1e-10)
+    float c = x < lo ? lo : x;
+    c = c > hi ? hi : c;
+    return (c - lo) / den;
+}
+__device__ __forceinline__ float clip11(float v)
+{
+    v = v < -1.0f ? -1.0f : v;
+    return v > 1.0f ? 1.0f : v;
+}
+__device__ __forceinline__ float ratio_index(float num, float den)
+{
+    // zeros_like; out[mask] = num/den with mask = den > 0.001 (False for NaN); clip to [-1, 1]
+    float v = den > 0.001f ? num / den : 0.0f;
+    return clip11(v);
+}
+
+struct k2_args {
+    const float *band[5];
+    float *out[7];
+    float *norm[5];
+    float lo[5], hi[5], den[5];
+    int normalise;
+};
+
+// o: ndvi, evi, msavi, ndwi, mndwi, ndbi, bsi
+__device__ __forceinline__ void k2_pixel(const float nb[5], float o[7])
+{
+    const float blue = nb[0], green = nb[1], red = nb[2], nir = nb[3], swir = nb[4];
+    const float nmr = nir - red;
+    o[0] = ratio_index(nmr, nir + red);
+    {   // indices.py:86-93  nir + C1*red - C2*blue + L ;  G*(nir-red)/den
+        float den = nir + 6.0f * red;
+        den = den - 7.5f * blue;
+        den = den + 1.0f;
+        o[1] = ratio_index(2.5f * nmr, den);
+    }
+    {   // indices.py:109-112  (a - sqrt(a**2 - 8*(nir-red))) / 2
+        const float a = 2.0f * nir + 1.0f;
+        float r = a * a - 8.0f * nmr;
+        float m = (a - sqrtf(r)) / 2.0f;
+        o[2] = clip11(m);  // NaN propagates like np.clip
+    }
+    o[3] = ratio_index(green - nir, green + nir);
+    o[4] = ratio_index(green - swir, green + swir);
+    o[5] = ratio_index(swir - nir, swir + nir);
+    {
+        const float a = swir + red, b = nir + blue;
+        o[6] = ratio_index(a - b, a + b);
+    }
+}
+
+__global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n)
+{
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
+        float4 b[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) b[j] = reinterpret_cast<const float4 *>(a.band[j])[i];
+        float nb[4][5], o[4][7];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const float v[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+            for (int p = 0; p < 4; p++) nb[p][j] = a.normalise ? norm1(v[p], a.lo[j], a.hi[j], a.den[j]) : v[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) k2_pixel(nb[p], o[p]);
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (a.out[j]) reinterpret_cast<float4 *>(a.out[j])[i] = make_float4(o[0][j], o[1][j], o[2][j], o[3][j]);
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (a.norm[j]) reinterpret_cast<float4 *>(a.norm[j])[i] = make_float4(nb[0][j], nb[1][j], nb[2][j], nb[3][j]);
+    }
+    // tail (n % 4 pixels)
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * K2_THREADS + threadIdx.x;
+    if (t < n) {
+        float nb[5], o[7];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            float v = a.band[j][t];
+            nb[j] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
+        }
+        k2_pixel(nb, o);
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (a.out[j]) a.out[j][t] = o[j];
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (a.norm[j]) a.norm[j][t] = nb[j];
+    }
+}
+
+__global__ __launch_bounds__(K2_THREADS) void k2_normalize(const float *__restrict__ x, float *__restrict__ y, int64_t n,
+                                                          float lo, float hi, float den)
+{
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
+        float4 v = reinterpret_cast<const float4 *>(x)[i];
+        v.x = norm1(v.x, lo, hi, den); v.y = norm1(v.y, lo, hi, den);
+        v.z = norm1(v.z, lo, hi, den); v.w = norm1(v.w, lo, hi, den);
+        reinterpret_cast<float4 *>(y)[i] = v;
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * K2_THREADS + threadIdx.x;
+    if (t < n) y[t] = norm1(x[t], lo, hi, den);
+}
+
+__global__ __launch_bounds__(K2_THREADS) void k2_quantize(const float *__restrict__ x, uint8_t *__restrict__ q, int64_t n, float mult)
+{
+    // (x * mult).astype(np.uint8): truncation toward zero of a value in [0, mult]
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
+        float4 v = reinterpret_cast<const float4 *>(x)[i];
+        uchar4 o;
+        o.x = (uint8_t)(int)(v.x * mult); o.y = (uint8_t)(int)(v.y * mult);
+        o.z = (uint8_t)(int)(v.z * mult); o.w = (uint8_t)(int)(v.w * mult);
+        reinterpret_cast<uchar4 *>(q)[i] = o;
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * K2_THREADS + threadIdx.x;
+    if (t < n) q[t] = (uint8_t)(int)(x[t] * mult);
+}
+
+static int stream_grid(int64_t n4)
+{
+    return (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n4, K2_THREADS)));
+}
+
+static inline float norm_den(float lo, float hi)
+{
+    volatile float d = hi - lo;
+    volatile float e = d + 1e-10f;
+    return e;
+}
+
+extern "C" int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize: bad arguments");
+    if ((((uintptr_t)d_x | (uintptr_t)d_out) & 15) != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize: planes must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "indices");
+        hipLaunchKernelGGL(k2_normalize, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_out, n, lo, hi, norm_den(lo, hi));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
+                                          float *const *d_out, float *const *d_norm)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_bands || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: bad arguments");
+    k2_args a;
+    memset(&a, 0, sizeof(a));
+    for (int j = 0; j < 5; j++) {
+        if (!d_bands[j] || ((uintptr_t)d_bands[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: band %d null or unaligned", j);
+        a.band[j] = d_bands[j];
+        a.norm[j] = d_norm ? d_norm[j] : nullptr;
+        if (a.norm[j] && ((uintptr_t)a.norm[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: norm plane unaligned");
+        if (lohi) {
+            a.lo[j] = lohi[2 * j];
+            a.hi[j] = lohi[2 * j + 1];
+            a.den[j] = norm_den(a.lo[j], a.hi[j]);
+        }
+    }
+    a.normalise = lohi != nullptr;
+    for (int j = 0; j < 7; j++) {
+        a.out[j] = d_out[j];
+        if (a.out[j] && ((uintptr_t)a.out[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: output plane unaligned");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "indices");
+        hipLaunchKernelGGL(k2_indices, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, uint8_t *d_q)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_q || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "quantize: bad arguments");
+    if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 3)) return rs_fail(ctx, RSSEG_ERR_INVALID, "quantize: unaligned plane");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "indices");
+        hipLaunchKernelGGL(k2_quantize, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}

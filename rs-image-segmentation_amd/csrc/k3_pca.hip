@@ -1,0 +1,320 @@
+// K3 — PCA of the band stack: RobustScaler transform on the fly, exact Gram / mean accumulation,
+// 7x7 symmetric eigen-solve on the host, projection kernel.
+//
+// Replaces perform_pca (reference modules/features/indices.py:205-246):
+//   RobustScaler.transform   X -= center_ (float32);  X /= scale_ (float64 divisor, result float32)
+//                            sklearn/preprocessing/_data.py:1716-1718
+//   PCA._fit_full, covariance_eigh   sklearn/decomposition/_pca.py:560, 600-646
+//   PCA._transform                    sklearn/decomposition/_base.py:148-155
+// The scaled matrix X (N x B) is never materialised: both kernels recompute it from the band planes
+// (28 B/px read each; the projection writes 4 B/px per component).  The Gram matrix is accumulated
+// as exact fixed-point sums (independent of launch geometry / sharding); B = 7 makes this 3.5 flop/B,
+// i.e. HBM-bound, so it runs on the vector ALUs next to the loads rather than through MFMA tiles.
+#include <cmath>
+
+#include "common.h"
+
+#define PCA_THREADS 256
+#define PCA_MAXB 8
+#define PCA_NACC (PCA_MAXB + PCA_MAXB * (PCA_MAXB + 1) / 2)
+
+struct pca_args {
+    const float *band[PCA_MAXB];
+    float center[PCA_MAXB];
+    double scale[PCA_MAXB];
+    int nb;
+    int scaled;
+    double fx_scale;  // 2^Q used for the fixed-point accumulation of x and x*x
+};
+
+__device__ __forceinline__ float pca_x(const pca_args &a, int b, float v)
+{
+    if (!a.scaled) return v;
+    float d = v - a.center[b];
+    return (float)((double)d / a.scale[b]);
+}
+
+__device__ __forceinline__ long long to_fixed_q(double x, double s)
+{
+    double d = fma(x, s, FX_MAGIC);
+    return __double_as_longlong(d) - __double_as_longlong(FX_MAGIC);
+}
+
+// partial[blk][PCA_NACC][2] ({hi, lo} 32-bit limb sums): sums of x_b (nb entries) then x_a*x_b for a <= b (row-major upper triangle)
+__global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, long long *__restrict__ partial)
+{
+    long long acc[PCA_NACC];
+#pragma unroll
+    for (int i = 0; i < PCA_NACC; i++) acc[i] = 0;
+    const int64_t n4 = n >> 2;
+    auto pixel = [&](const float *v) {
+        float x[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) x[b] = b < a.nb ? pca_x(a, b, v[b]) : 0.0f;
+        int t = PCA_MAXB;
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) {
+            acc[b] += to_fixed_q((double)x[b], a.fx_scale);
+#pragma unroll
+            for (int c = b; c < PCA_MAXB; c++) {
+                // product of two float32 values is exact in float64
+                acc[t] += to_fixed_q((double)x[b] * (double)x[c], a.fx_scale);
+                t++;
+            }
+        }
+    };
+    for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
+        float4 v[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++)
+            v[b] = b < a.nb ? reinterpret_cast<const float4 *>(a.band[b])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float p0[PCA_MAXB], p1[PCA_MAXB], p2[PCA_MAXB], p3[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+        pixel(p0); pixel(p1); pixel(p2); pixel(p3);
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
+    if (t < n) {
+        float p[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) p[b] = b < a.nb ? a.band[b][t] : 0.0f;
+        pixel(p);
+    }
+    // per-thread sums stay below 2^61; split into 32-bit limbs before the cross-lane sums
+    __shared__ long long sh[4][2 * PCA_NACC];
+#pragma unroll
+    for (int i = 0; i < PCA_NACC; i++) {
+        long long hi = wave_sum(acc[i] >> 32), lo = wave_sum(acc[i] & 0xffffffffLL);
+        if (lane_id() == 0) { sh[threadIdx.x >> 6][2 * i] = hi; sh[threadIdx.x >> 6][2 * i + 1] = lo; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * PCA_NACC)
+        partial[(size_t)blockIdx.x * 2 * PCA_NACC + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+struct proj_args {
+    float comp[PCA_MAXB][PCA_MAXB];  // [component][band]
+    float offs[PCA_MAXB];            // mean @ components.T
+    float *out[PCA_MAXB];
+    int nc;
+};
+
+__global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args pr, int64_t n)
+{
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
+        float4 v[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++)
+            v[b] = b < a.nb ? reinterpret_cast<const float4 *>(a.band[b])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float x[4][PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) {
+            x[0][b] = b < a.nb ? pca_x(a, b, v[b].x) : 0.f;
+            x[1][b] = b < a.nb ? pca_x(a, b, v[b].y) : 0.f;
+            x[2][b] = b < a.nb ? pca_x(a, b, v[b].z) : 0.f;
+            x[3][b] = b < a.nb ? pca_x(a, b, v[b].w) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < PCA_MAXB; c++) {
+            if (c < pr.nc) {
+                float y[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < PCA_MAXB; b++)
+                        if (b < a.nb) s = __fmaf_rn(x[p][b], pr.comp[c][b], s);
+                    y[p] = s - pr.offs[c];
+                }
+                reinterpret_cast<float4 *>(pr.out[c])[i] = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
+    if (t < n) {
+        float x[PCA_MAXB];
+#pragma unroll
+        for (int b = 0; b < PCA_MAXB; b++) x[b] = b < a.nb ? pca_x(a, b, a.band[b][t]) : 0.f;
+        for (int c = 0; c < pr.nc; c++) {
+            float s = 0.f;
+            for (int b = 0; b < a.nb; b++) s = __fmaf_rn(x[b], pr.comp[c][b], s);
+            pr.out[c][t] = s - pr.offs[c];
+        }
+    }
+}
+
+// cyclic Jacobi for a small symmetric matrix (float64).  V columns = eigenvectors.
+static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][PCA_MAXB], double *w)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) w[i] = A[i][i];
+}
+
+extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local,
+                                           const float *center, const double *scale, int n_components, float *const *d_out,
+                                           float *components, float *explained_variance_ratio, float *mean,
+                                           float *explained_variance)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_bands || nb < 1 || nb > PCA_MAXB || n_components < 1 || n_components > nb || n_local < 0)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: bad arguments (nb=%d, n_components=%d)", nb, n_components);
+    if ((center == nullptr) != (scale == nullptr)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: center and scale must both be given or both be NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    pca_args a;
+    memset(&a, 0, sizeof(a));
+    a.nb = nb;
+    a.scaled = center != nullptr;
+    for (int b = 0; b < nb; b++) {
+        if (!d_bands[b] || ((uintptr_t)d_bands[b] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: band %d null or unaligned", b);
+        a.band[b] = d_bands[b];
+        a.center[b] = center ? center[b] : 0.f;
+        a.scale[b] = scale ? scale[b] : 1.0;
+    }
+    // bound on |x'| from the band ranges (one cheap pass would also do; the hot path feeds normalised
+    // bands in [0,1], so bound with that and the scaler): |x'| <= max(|0-c|,|1-c|)/s
+    double bound = 1.0;
+    for (int b = 0; b < nb; b++) {
+        double c = a.scaled ? (double)a.center[b] : 0.0, s = a.scaled ? a.scale[b] : 1.0;
+        bound = std::max(bound, std::max(std::fabs(0.0 - c), std::fabs(1.0 - c)) / s * 1.000001);
+    }
+    int e2;
+    std::frexp(bound * bound, &e2);           // bound^2 < 2^e2
+    const int Q = std::min(38, 48 - e2);      // |x*x| * 2^Q < 2^48: 4096 pixels per thread stay below 2^60
+    if (Q < 8) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: scaled band range too large for exact accumulation (bound %.3g)", bound);
+    a.fx_scale = std::ldexp(1.0, Q);
+
+    if (n_local > ((int64_t)1 << 31)) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: more than 2^31 pixels per GPU");
+    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS)));
+    RSCHK(ws_reserve(ctx, sizeof(long long) * (size_t)grid * 2 * PCA_NACC));
+    RSCHK(pin_reserve(ctx, sizeof(long long) * (size_t)grid * 2 * PCA_NACC));
+    long long *d_part = (long long *)ctx->d_ws;
+    {
+        prof_scope ps(ctx, "gram");
+        hipLaunchKernelGGL(k3_gram, dim3(grid), dim3(PCA_THREADS), 0, ctx->stream, a, n_local, d_part);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)grid * 2 * PCA_NACC, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    typedef __int128 i128;
+    long long lim[2 * PCA_NACC + 2];
+    {
+        const long long *hp = (const long long *)ctx->h_pin;
+        for (int i = 0; i < PCA_NACC; i++) {
+            i128 s = 0;
+            for (int g = 0; g < grid; g++)
+                s += ((i128)hp[((size_t)g * PCA_NACC + i) * 2] << 32) + (i128)hp[((size_t)g * PCA_NACC + i) * 2 + 1];
+            lim[2 * i] = (long long)(s >> 32);
+            lim[2 * i + 1] = (long long)(s & 0xffffffffLL);
+        }
+        lim[2 * PCA_NACC] = n_local;
+        lim[2 * PCA_NACC + 1] = 0;
+    }
+    RSCHK(comm_allreduce_host(ctx, lim, 2 * PCA_NACC + 2, RSSEG_I64, RSSEG_SUM));
+    const int64_t N = lim[2 * PCA_NACC];
+    if (N < 2) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: needs at least 2 samples");
+    const double inv = std::ldexp(1.0, -Q);
+    auto val = [&](int i) { return (double)((((i128)lim[2 * i]) << 32) + (i128)lim[2 * i + 1]) * inv; };
+    // sklearn's float32 steps on exactly accumulated sums
+    float mu[PCA_MAXB];
+    for (int b = 0; b < nb; b++) {
+        volatile float s = (float)val(b);
+        volatile float m = s / (float)N;
+        mu[b] = m;
+    }
+    double Cd[PCA_MAXB][PCA_MAXB];
+    {
+        int t = PCA_MAXB;
+        for (int b = 0; b < PCA_MAXB; b++)
+            for (int c = b; c < PCA_MAXB; c++, t++) {
+                if (b >= nb || c >= nb) continue;
+                volatile float g = (float)val(t);                // X.T @ X
+                volatile float nm = (float)N * mu[b];            // n_samples * mean (column)
+                volatile float nmm = nm * mu[c];                 //   ... * mean (row)
+                volatile float cc = g - nmm;                     // C -= ...
+                volatile float cv = cc / (float)(N - 1);         // C /= n_samples - 1
+                Cd[b][c] = Cd[c][b] = (double)cv;
+            }
+    }
+    double V[PCA_MAXB][PCA_MAXB], w[PCA_MAXB];
+    jacobi_eigh(nb, Cd, V, w);
+    int order[PCA_MAXB];
+    for (int i = 0; i < nb; i++) order[i] = i;
+    std::stable_sort(order, order + nb, [&](int x, int y) { return w[x] > w[y]; });
+    float ev[PCA_MAXB], total = 0.f;
+    for (int i = 0; i < nb; i++) {
+        float e = (float)w[order[i]];
+        ev[i] = e < 0.f ? 0.f : e;
+    }
+    {
+        volatile float t = 0.f;
+        for (int i = 0; i < nb; i++) t = t + ev[i];
+        total = t;
+    }
+    proj_args pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.nc = n_components;
+    for (int c = 0; c < n_components; c++) {
+        float row[PCA_MAXB];
+        int am = 0;
+        for (int b = 0; b < nb; b++) {
+            row[b] = (float)V[b][order[c]];
+            if (std::fabs(row[b]) > std::fabs(row[am])) am = b;
+        }
+        const float sg = row[am] < 0.f ? -1.f : 1.f;  // svd_flip(u_based_decision=False)
+        volatile float o = 0.f;
+        for (int b = 0; b < nb; b++) {
+            pr.comp[c][b] = row[b] * sg;
+            o = fmaf(mu[b], pr.comp[c][b], o);
+            if (components) components[c * nb + b] = pr.comp[c][b];
+        }
+        pr.offs[c] = o;
+        if (explained_variance) explained_variance[c] = ev[c];
+        if (explained_variance_ratio) explained_variance_ratio[c] = ev[c] / total;
+        if (d_out) {
+            if (!d_out[c] || ((uintptr_t)d_out[c] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: output plane %d null or unaligned", c);
+            pr.out[c] = d_out[c];
+        }
+    }
+    if (mean)
+        for (int b = 0; b < nb; b++) mean[b] = mu[b];
+    if (d_out && n_local > 0) {
+        {
+            prof_scope ps(ctx, "project");
+            hipLaunchKernelGGL(k3_project, dim3((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS)))),
+                               dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return stream_sync(ctx);
+}

@@ -1,0 +1,1088 @@
+// K9/K10 — MinMax scaling, k-means++ seeding and Lloyd iterations on feature-planar rasters.
+//
+// Replaces unsupervised_kmeans_classification (reference modules/features/extract.py:568-579), i.e.
+// sklearn 1.7.2 MinMaxScaler + KMeans(random_state, n_init=1, init='k-means++').fit_predict:
+//   sklearn/preprocessing/_data.py:508-522,555-556   sklearn/cluster/_kmeans.py:213-287,699-748,1454-1530
+//   sklearn/cluster/_k_means_lloyd.pyx:29-218        sklearn/cluster/_k_means_common.pyx:167-311
+//   sklearn/metrics/pairwise.py:391-437,582-644
+//
+// Numerics contract (identical to oracle/kmeans_impl.h, which tests compare against bit for bit):
+//   * the value clustered is fl(fl(fl(x*scale)+min_) - mean) in the input type T, recomputed on the
+//     fly from the raw planes — the scaled matrix is never materialised in HBM;
+//   * per-pixel arithmetic keeps sklearn's order: Lloyd distances are fma chains in T
+//     (||c||^2 - 2 x.c), k-means++ distances are the float64 "upcast" formula rounded to T;
+//   * every reduction over pixels (means, variances, potentials, per-cluster sums) is an exact
+//     fixed-point sum (quantum 2^-40), so results do not depend on the launch geometry, on atomics
+//     or on how the raster is sharded over GPUs.
+//
+// Data movement per Lloyd iteration: F planes read once (4F B/px for float32) + 1 B/px label read
+// + 1 B/px label write; the tile is staged in LDS so the per-cluster accumulation re-reads it
+// on chip.  HBM-bound.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "common.h"
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+#define KM_THREADS 256
+#define KM_TILES_PER_CHUNK 16
+
+template <typename T> struct vt;
+template <> struct vt<float> {
+    typedef float4 vec;
+    static constexpr int PXL = 4;
+};
+template <> struct vt<double> {
+    typedef double2 vec;
+    static constexpr int PXL = 2;
+};
+template <typename T> __host__ __device__ constexpr int km_tile() { return KM_THREADS * vt<T>::PXL; }
+template <typename T> __host__ __device__ constexpr int km_chunk() { return km_tile<T>() * KM_TILES_PER_CHUNK; }
+
+struct planes_t {
+    const void *p[RSSEG_MAX_FEATURES];
+};
+
+// per-feature scaler parameters, in T, resident in device memory (uniform loads)
+template <typename T> struct scaler_t {
+    T scale[RSSEG_MAX_FEATURES];
+    T minv[RSSEG_MAX_FEATURES];
+    T mean[RSSEG_MAX_FEATURES];
+};
+
+template <typename T> __device__ __forceinline__ T tfma(T a, T b, T c);
+template <> __device__ __forceinline__ float tfma<float>(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+template <> __device__ __forceinline__ double tfma<double>(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T> __device__ __forceinline__ void unpack(const typename vt<T>::vec &v, T *o);
+template <> __device__ __forceinline__ void unpack<float>(const float4 &v, float *o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpack<double>(const double2 &v, double *o) { o[0] = v.x; o[1] = v.y; }
+
+// loads PXL consecutive pixels of plane f starting at pixel `base` (bounds-checked against n)
+template <typename T>
+__device__ __forceinline__ void load_px(const void *plane, int64_t base, int64_t n, T *o)
+{
+    constexpr int PXL = vt<T>::PXL;
+    const T *p = reinterpret_cast<const T *>(plane);
+    if (base + PXL <= n) {
+        typename vt<T>::vec v = *reinterpret_cast<const typename vt<T>::vec *>(p + base);
+        unpack<T>(v, o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXL; i++) o[i] = (base + i < n) ? p[base + i] : (T)0;
+    }
+}
+
+template <typename T> __device__ __forceinline__ T scaled(T x, T sc, T mn)
+{
+    if (x != x) x = (T)0;  // extract.py:548-556  NaN -> 0
+    T xs = x * sc;
+    return xs + mn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass A: per-feature min / max (NaN -> 0).  grid (nblk, F); partial[f][blk] = {min, max}
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void km_minmax(planes_t pl, int64_t n, T *__restrict__ pmin, T *__restrict__ pmax)
+{
+    constexpr int PXL = vt<T>::PXL;
+    const int f = blockIdx.y;
+    T mn = (T)INFINITY, mx = (T)-INFINITY;
+    for (int64_t base = ((int64_t)blockIdx.x * KM_THREADS + threadIdx.x) * PXL; base < n; base += (int64_t)gridDim.x * KM_THREADS * PXL) {
+        T v[PXL];
+        load_px<T>(pl.p[f], base, n, v);
+#pragma unroll
+        for (int i = 0; i < PXL; i++)
+            if (base + i < n) {
+                T x = v[i];
+                if (x != x) x = (T)0;
+                mn = x < mn ? x : mn;
+                mx = x > mx ? x : mx;
+            }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    __shared__ T smn[4], smx[4];
+    if (lane_id() == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
+        pmin[(size_t)f * gridDim.x + blockIdx.x] = mn;
+        pmax[(size_t)f * gridDim.x + blockIdx.x] = mx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass B/C: exact sums.  MODE 0: sum fixed(xs).  MODE 1: sum fixed(fl((xs-m)*(xs-m))).
+// grid (nblk, F); partial[f][blk] int64
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(KM_THREADS) void km_moment(planes_t pl, int64_t n, const scaler_t<T> *__restrict__ sp,
+                                                        long long *__restrict__ partial)
+{
+    constexpr int PXL = vt<T>::PXL;
+    const int f = blockIdx.y;
+    const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+    long long acc = 0;
+    for (int64_t base = ((int64_t)blockIdx.x * KM_THREADS + threadIdx.x) * PXL; base < n; base += (int64_t)gridDim.x * KM_THREADS * PXL) {
+        T v[PXL];
+        load_px<T>(pl.p[f], base, n, v);
+#pragma unroll
+        for (int i = 0; i < PXL; i++)
+            if (base + i < n) {
+                T xs = scaled<T>(v[i], sc, mnv);
+                if (MODE == 0) {
+                    acc += to_fixed40((double)xs);
+                } else {
+                    T d = xs - me;
+                    T dd = d * d;
+                    acc += to_fixed40((double)dd);
+                }
+            }
+    }
+    acc = wave_sum(acc);
+    __shared__ long long sacc[4];
+    if (lane_id() == 0) sacc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)f * gridDim.x + blockIdx.x] = sacc[0] + sacc[1] + sacc[2] + sacc[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather one scaled+centred row (F values of T) at local pixel index idx
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void km_gather_row(planes_t pl, int F, int64_t idx, const scaler_t<T> *__restrict__ sp, T *__restrict__ out)
+{
+    const int f = threadIdx.x;
+    if (f < F) {
+        T x = reinterpret_cast<const T *>(pl.p[f])[idx];
+        out[f] = scaled<T>(x, sp->scale[f], sp->minv[f]) - sp->mean[f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ passes.  cand: [L][F] rows in T, cc: [L] float64 squared norms.
+//   MODE 0 (init):   closest = d2(cand0, x)                  ; partial[chunk] = sum fixed(closest)
+//   MODE 1 (eval):   for l < L: m_l = min(closest, d2(cand_l, x)); partial[l][chunk] = sum fixed(m_l)
+//   MODE 2 (update): closest = min(closest, d2(cand0, x))    ; partial[chunk] = sum fixed(closest)
+// one workgroup per chunk (km_chunk<T>() pixels), so partial[] is also the prefix table used to
+// locate the sampled pixel (np.searchsorted on stable_cumsum, _kmeans.py:243-246).
+// ------------------------------------------------------------------------------------------------
+#define KPP_MAXL 8
+template <typename T, int MODE>
+__global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t n, const scaler_t<T> *__restrict__ sp,
+                                                     const T *__restrict__ cand, const double *__restrict__ cc, int L,
+                                                     T *__restrict__ closest, unsigned long long *__restrict__ partial,
+                                                     int64_t nchunks)
+{
+    constexpr int PXL = vt<T>::PXL;
+    constexpr int NL = MODE == 1 ? KPP_MAXL : 1;
+    unsigned long long acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) acc[l] = 0;
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t base = chunk0 + (int64_t)t * km_tile<T>() + (int64_t)threadIdx.x * PXL;
+        if (base >= n) break;
+        double dot[NL][PXL], yy[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            yy[p] = 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; l++) dot[l][p] = 0.0;
+        }
+        for (int f = 0; f < F; f++) {
+            T v[PXL];
+            load_px<T>(pl.p[f], base, n, v);
+            const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) {
+                const double y = (double)(scaled<T>(v[p], sc, mnv) - me);
+                yy[p] = fma(y, y, yy[p]);
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    if (l < L) dot[l][p] = fma((double)cand[l * F + f], y, dot[l][p]);
+            }
+        }
+        T cl[PXL];
+        if (MODE != 0) load_px<T>(closest, base, n, cl);
+        T outv[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                if (l < L) {
+                    double d = -2.0 * dot[l][p];
+                    d = d + cc[l];
+                    d = d + yy[p];
+                    T dt = (T)d;
+                    dt = dt > (T)0 ? dt : (T)0;  // np.maximum(distances, 0)
+                    if (MODE != 0) dt = cl[p] < dt ? cl[p] : dt;  // np.minimum(closest, d)
+                    if (base + p < n) acc[l] += (unsigned long long)to_fixed40((double)dt);
+                    if (l == 0) outv[p] = dt;
+                }
+            }
+        }
+        if (MODE != 1) {
+            if (base + PXL <= n) {
+                typename vt<T>::vec o;
+                if constexpr (PXL == 4) o = make_float4(outv[0], outv[1], outv[2], outv[3]);
+                else o = make_double2(outv[0], outv[1]);
+                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+            } else {
+                for (int p = 0; p < PXL; p++)
+                    if (base + p < n) closest[base + p] = outv[p];
+            }
+        }
+    }
+    __shared__ unsigned long long sacc[4][NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        unsigned long long s = wave_sum(acc[l]);
+        if (lane_id() == 0) sacc[threadIdx.x >> 6][l] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL && (int)threadIdx.x < (MODE == 1 ? L : 1))
+        partial[(size_t)threadIdx.x * nchunks + blockIdx.x] =
+            sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lloyd iteration (lloyd_iter_chunked_dense + _update_chunk_dense).
+// cenT: [F][KMAX] centres (transposed so one scalar load brings the KMAX values of a feature),
+// csq: [KMAX].  labels: uint8 per pixel.  partial (UPDATE only): [(KMAX*F + KMAX + 1)][nchunks]
+// int64: per-cluster fixed-point sums, per-cluster counts, number of changed labels.
+// LDS: tile[F][TILE] of scaled+centred values + per-wave scratch.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KMAX, bool UPDATE>
+__global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k, int64_t n,
+                                                       const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
+                                                       const T *__restrict__ csq, uint8_t *__restrict__ labels,
+                                                       long long *__restrict__ partial, int64_t nchunks)
+{
+    constexpr int PXL = vt<T>::PXL;
+    constexpr int TILE = KM_THREADS * PXL;
+    extern __shared__ __align__(16) char smem[];
+    T *tile = reinterpret_cast<T *>(smem);                                   // [F][TILE]
+    uint8_t *tlab = reinterpret_cast<uint8_t *>(tile + (size_t)F * TILE);    // [TILE]
+    long long *S = reinterpret_cast<long long *>(tlab + TILE);               // [KMAX][F]
+    int *cnt = reinterpret_cast<int *>(S + (size_t)KMAX * F);                // [KMAX]
+    int *changed = cnt + KMAX;                                               // [1]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (UPDATE) {
+        for (int i = threadIdx.x; i < KMAX * F; i += KM_THREADS) S[i] = 0;
+        if (threadIdx.x < KMAX) cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) *changed = 0;
+    }
+    T cs[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) cs[j] = csq[j];
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    int my_changed = 0;
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t tbase = chunk0 + (int64_t)t * TILE;
+        if (tbase >= n) break;
+        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+        if (UPDATE) __syncthreads();  // previous tile's phase B done (and initialisation visible)
+        T acc[KMAX][PXL];
+#pragma unroll
+        for (int j = 0; j < KMAX; j++)
+#pragma unroll
+            for (int p = 0; p < PXL; p++) acc[j][p] = (T)0;
+#pragma unroll 2
+        for (int f = 0; f < F; f++) {
+            T v[PXL];
+            if (base < n) load_px<T>(pl.p[f], base, n, v);
+            else {
+#pragma unroll
+                for (int p = 0; p < PXL; p++) v[p] = (T)0;
+            }
+            const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+            T xc[PXL];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) xc[p] = scaled<T>(v[p], sc, mnv) - me;
+            if (UPDATE) {
+                typename vt<T>::vec o;
+                if constexpr (PXL == 4) o = make_float4(xc[0], xc[1], xc[2], xc[3]);
+                else o = make_double2(xc[0], xc[1]);
+                *reinterpret_cast<typename vt<T>::vec *>(tile + (size_t)f * TILE + threadIdx.x * PXL) = o;
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; j++) {
+                const T c = cenT[f * KMAX + j];
+#pragma unroll
+                for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(xc[p], c, acc[j][p]);
+            }
+        }
+        // argmin with strict '<' (lowest index wins ties), _k_means_lloyd.pyx:206-213
+        uint8_t lab[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            T bd = tfma<T>((T)-2, acc[0][p], cs[0]);
+            int bl = 0;
+#pragma unroll
+            for (int j = 1; j < KMAX; j++) {
+                if (j < k) {
+                    T d = tfma<T>((T)-2, acc[j][p], cs[j]);
+                    if (d < bd) { bd = d; bl = j; }
+                }
+            }
+            lab[p] = (uint8_t)bl;
+        }
+        if (base < n) {
+            if (base + PXL <= n) {
+                if constexpr (PXL == 4) {
+                    uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
+                    my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
+                    *reinterpret_cast<uchar4 *>(labels + base) = make_uchar4(lab[0], lab[1], lab[2], lab[3]);
+                } else {
+                    uchar2 old = *reinterpret_cast<const uchar2 *>(labels + base);
+                    my_changed += (old.x != lab[0]) + (old.y != lab[1]);
+                    *reinterpret_cast<uchar2 *>(labels + base) = make_uchar2(lab[0], lab[1]);
+                }
+            } else {
+                for (int p = 0; p < PXL; p++)
+                    if (base + p < n) {
+                        my_changed += labels[base + p] != lab[p];
+                        labels[base + p] = lab[p];
+                    }
+            }
+        }
+        if (UPDATE) {
+#pragma unroll
+            for (int p = 0; p < PXL; p++) tlab[threadIdx.x * PXL + p] = (base + p < n) ? lab[p] : (uint8_t)255;
+            __syncthreads();
+            // phase B: wave w accumulates features w, w+4, ...; lanes sweep the tile
+            for (int f = wave; f < F; f += 4) {
+                for (int s = 0; s < TILE / (64 * PXL); s++) {
+                    const int px0 = (s * 64 + lane) * PXL;
+                    T xv[PXL];
+                    typename vt<T>::vec v = *reinterpret_cast<const typename vt<T>::vec *>(tile + (size_t)f * TILE + px0);
+                    unpack<T>(v, xv);
+                    uint8_t lb[PXL];
+#pragma unroll
+                    for (int p = 0; p < PXL; p++) lb[p] = tlab[px0 + p];
+                    long long q[PXL];
+#pragma unroll
+                    for (int p = 0; p < PXL; p++) q[p] = to_fixed40((double)xv[p]);
+                    for (int j = 0; j < k; j++) {
+                        long long v2 = 0;
+                        int c2 = 0;
+#pragma unroll
+                        for (int p = 0; p < PXL; p++) {
+                            const bool m = lb[p] == j;
+                            v2 += m ? q[p] : 0;
+                            c2 += m;
+                        }
+                        if (__any(c2 != 0)) {
+                            long long tot = wave_sum(v2);
+                            if (f == 0) {
+                                int ct = wave_sum(c2);
+                                if (lane == 0) cnt[j] += ct;
+                            }
+                            if (lane == 0) S[(size_t)j * F + f] += tot;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (UPDATE) {
+        int ch = wave_sum(my_changed);
+        if (lane == 0 && ch) atomicAdd(changed, ch);
+        __syncthreads();
+        const int M = KMAX * F + KMAX + 1;
+        for (int i = threadIdx.x; i < M; i += KM_THREADS) {
+            long long v;
+            if (i < KMAX * F) v = S[i];
+            else if (i < KMAX * F + KMAX) v = cnt[i - KMAX * F];
+            else v = *changed;
+            partial[(size_t)i * nchunks + blockIdx.x] = v;
+        }
+    }
+}
+
+// column sums of partial[M][nchunks] -> out[M][2] = {sum of (v >> 32), sum of (v & 0xffffffff)}
+__global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__restrict__ partial, int64_t nchunks,
+                                                            long long *__restrict__ out)
+{
+    const int m = blockIdx.x;
+    long long hi = 0, lo = 0;
+    for (int64_t c = threadIdx.x; c < nchunks; c += KM_THREADS) {
+        long long v = partial[(size_t)m * nchunks + c];
+        hi += v >> 32;
+        lo += v & 0xffffffffLL;
+    }
+    hi = wave_sum(hi);
+    lo = wave_sum(lo);
+    __shared__ long long sh[4], sl[4];
+    if (lane_id() == 0) { sh[threadIdx.x >> 6] = hi; sl[threadIdx.x >> 6] = lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * m] = sh[0] + sh[1] + sh[2] + sh[3];
+        out[2 * m + 1] = sl[0] + sl[1] + sl[2] + sl[3];
+    }
+}
+
+__global__ __launch_bounds__(KM_THREADS) void km_labels_out(const uint8_t *__restrict__ lab, int32_t *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * KM_THREADS) out[i] = lab[i];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+namespace {
+
+// MT19937 as seeded by numpy.random.RandomState(int) (init_genrand) — _kmeans.py:1465 check_random_state
+struct mt19937 {
+    uint32_t mt[624];
+    int idx;
+    explicit mt19937(uint32_t s)
+    {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    uint32_t next()
+    {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    double random_sample()  // genrand_res53
+    {
+        uint32_t a = next() >> 5, b = next() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+};
+
+// s_i = p + p + ... (i terms, sequential float64 additions starting from 0.0) in O(#binades).
+// This is np.cumsum of the constant probability vector inside RandomState.choice (mtrand: cdf = p.cumsum()).
+double seq_sum(double p, int64_t count)
+{
+    double s = 0.0;
+    int64_t left = count;
+    while (left > 0) {
+        double s1 = s + p;  // one real step
+        left--;
+        if (left == 0) return s1;
+        int e0, e1;
+        frexp(s, &e0);
+        frexp(s1, &e1);
+        s = s1;
+        if (s == 0.0) continue;
+        // probe the increment now in force; constant while the result stays in this binade
+        double s2 = s + p;
+        int e2;
+        frexp(s2, &e2);
+        if (e2 != e1) continue;  // next step leaves the binade: take it as a real step
+        const double d = s2 - s;  // exact (same binade)
+        if (d <= 0.0) return s;   // p no longer changes the sum
+        const double top = ldexp(1.0, e1);  // exclusive upper bound of the binade
+        // largest j with s + j*d < top
+        double jf = floor((top - s) / d);
+        int64_t j = (int64_t)jf;
+        while (j > 0 && s + (double)j * d >= top) j--;
+        // rounding of the tie case alternates only on the first step, which was taken for real above;
+        // verify the increment after that step, fall back to single steps if it differs
+        double s3 = s2 + p;
+        int e3;
+        frexp(s3, &e3);
+        if (e3 == e1 && (s3 - s2) != d) {
+            s = s2;
+            left--;
+            continue;
+        }
+        if (j > left) j = left;
+        if (j <= 0) continue;
+        s = s + (double)j * d;  // exact: multiples of the binade's ulp
+        left -= j;
+    }
+    return s;
+}
+
+// RandomState.choice(n, p = ones/ones.sum()) for one draw u (mtrand.pyx: cdf = p.cumsum(); cdf /= cdf[-1];
+// idx = cdf.searchsorted(u, side='right'))
+int64_t uniform_choice(int64_t n, int dtype, double u)
+{
+    double p;
+    if (dtype == RSSEG_F32) {
+        float s = (float)n;
+        float pf = 1.0f / s;
+        p = (double)pf;
+    } else {
+        p = 1.0 / (double)n;
+    }
+    const double total = seq_sum(p, n);
+    int64_t lo = 0, hi = n;  // smallest idx in [0, n] with cdf[idx] > u
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        double c = seq_sum(p, mid + 1) / total;
+        if (c > u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
+template <typename T> T np_pairwise_sum(const T *a, int n)
+{
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; i++) res = res + a[i];
+        return res;
+    }
+    T r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] = r[j] + a[i + j];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+}
+
+template <typename T> T fixed_to_T(i128 s) { return (T)((double)s * (1.0 / 1099511627776.0)); }
+
+template <typename T> struct teps;
+template <> struct teps<float> { static constexpr float v = 1.1920928955078125e-07f; };
+template <> struct teps<double> { static constexpr double v = 2.220446049250313e-16; };
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// combine {hi, lo} limb sums (km_reduce_cols) into one signed 128-bit value
+i128 limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
+
+template <typename T, int KMAX>
+void launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
+                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial)
+{
+    if (update)
+        hipLaunchKernelGGL((km_lloyd<T, KMAX, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
+                           cenT, csq, labels, partial, nchunks);
+    else
+        hipLaunchKernelGGL((km_lloyd<T, KMAX, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
+                           cenT, csq, labels, partial, nchunks);
+}
+
+template <typename T, int KMAX> int set_lloyd_attr(rsseg_ctx *ctx, size_t lds)
+{
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return RSSEG_OK;
+}
+
+template <typename T>
+int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, int k, uint32_t seed, int max_iter, double tol_in,
+               int32_t *d_labels, double *centers_out, rsseg_kmeans_info *info)
+{
+    const double t_start = now_ms();
+    const int KMAX = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
+    const int L = 2 + (int)std::log((double)k);
+    if (L > KPP_MAXL) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: too many local trials");
+    constexpr int TILE = km_tile<T>();
+    constexpr int CHUNK = km_chunk<T>();
+    const int64_t nchunks = std::max<int64_t>(1, ceil_div64(n, CHUNK));
+    const int nblk = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n, (int64_t)KM_THREADS * vt<T>::PXL)));
+    const int M = KMAX * F + KMAX + 1;
+
+    // ---- rank geometry ----
+    int64_t n_all[RSSEG_MAX_RANKS] = {0};
+    n_all[ctx->rank] = n;
+    RSCHK(comm_allreduce_host(ctx, n_all, ctx->world, RSSEG_I64, RSSEG_SUM));
+    int64_t N = 0, offset = 0;
+    for (int r = 0; r < ctx->world; r++) {
+        if (r < ctx->rank) offset += n_all[r];
+        N += n_all[r];
+    }
+    if (N <= 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: no pixels");
+    if (N < k) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_samples=%lld should be >= n_clusters=%d", (long long)N, k);
+
+    // ---- workspace layout ----
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_sp = carve(sizeof(scaler_t<T>));
+    const size_t o_cen = carve(sizeof(T) * KMAX * RSSEG_MAX_FEATURES);
+    const size_t o_csq = carve(sizeof(T) * KMAX);
+    const size_t o_cand = carve(sizeof(T) * KPP_MAXL * RSSEG_MAX_FEATURES);
+    const size_t o_cc = carve(sizeof(double) * KPP_MAXL);
+    const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
+    const size_t o_red = carve(sizeof(long long) * 2 * M);
+    const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
+    const size_t o_mom = carve(sizeof(long long) * (size_t)nblk * F);
+    const size_t o_part = carve(sizeof(long long) * std::max<size_t>((size_t)M, KPP_MAXL) * (size_t)nchunks);
+    const size_t o_closest = carve(sizeof(T) * (size_t)std::max<int64_t>(n, 1) + 64);
+    const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
+    RSCHK(ws_reserve(ctx, off));
+    const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
+                                              sizeof(long long) * KPP_MAXL * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
+                                              sizeof(long long) * 2 * (size_t)M, (size_t)65536});
+    RSCHK(pin_reserve(ctx, pin_need));
+    char *ws = ctx->d_ws;
+    scaler_t<T> *d_sp = (scaler_t<T> *)(ws + o_sp);
+    T *d_cen = (T *)(ws + o_cen);
+    T *d_csq = (T *)(ws + o_csq);
+    T *d_cand = (T *)(ws + o_cand);
+    double *d_cc = (double *)(ws + o_cc);
+    T *d_row = (T *)(ws + o_row);
+    long long *d_red = (long long *)(ws + o_red);
+    T *d_mm = (T *)(ws + o_mm);
+    long long *d_mom = (long long *)(ws + o_mom);
+    long long *d_part = (long long *)(ws + o_part);
+    T *d_closest = (T *)(ws + o_closest);
+    uint8_t *d_lab = (uint8_t *)(ws + o_lab);
+    hipStream_t st = ctx->stream;
+
+    planes_t pl;
+    memset(&pl, 0, sizeof(pl));
+    for (int f = 0; f < F; f++) {
+        if (!d_planes[f] || ((uintptr_t)d_planes[f] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: plane %d null or not 16-byte aligned", f);
+        pl.p[f] = d_planes[f];
+    }
+
+    // ---- MinMaxScaler.fit ----
+    scaler_t<T> sp;
+    memset(&sp, 0, sizeof(sp));
+    {
+        if (n > 0) {
+            hipLaunchKernelGGL((km_minmax<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_mm, d_mm + (size_t)nblk * F);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mm, sizeof(T) * 2 * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+        }
+        const T *hmn = (const T *)ctx->h_pin, *hmx = hmn + (size_t)nblk * F;
+        double mm[2 * RSSEG_MAX_FEATURES];
+        for (int f = 0; f < F; f++) {
+            T mn = (T)INFINITY, mx = (T)-INFINITY;
+            if (n > 0)
+                for (int b = 0; b < nblk; b++) {
+                    mn = std::min(mn, hmn[(size_t)f * nblk + b]);
+                    mx = std::max(mx, hmx[(size_t)f * nblk + b]);
+                }
+            mm[f] = -(double)mn;  // MAX-reduce of the negated minimum
+            mm[F + f] = (double)mx;
+        }
+        RSCHK(comm_allreduce_host(ctx, mm, 2 * F, RSSEG_F64, RSSEG_MAX));
+        for (int f = 0; f < F; f++) {
+            volatile T mn = (T)(-mm[f]), mx = (T)mm[F + f];
+            volatile T range = mx - mn;
+            if (range < (T)10 * teps<T>::v) range = (T)1;  // _handle_zeros_in_scale
+            volatile T sc = (T)1 / range;
+            volatile T t = mn * sc;
+            volatile T mv = (T)0 - t;
+            sp.scale[f] = sc;
+            sp.minv[f] = mv;
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
+
+    // ---- X.mean(axis=0) and np.var(X, axis=0) with exact sums ----
+    const T Nt = (T)N;
+    auto moment_pass = [&](int mode, i128 *sums) -> int {
+        if (n > 0) {
+            if (mode == 0) hipLaunchKernelGGL((km_moment<T, 0>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            else hipLaunchKernelGGL((km_moment<T, 1>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, sizeof(long long) * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+        }
+        long long lim[2 * RSSEG_MAX_FEATURES];
+        const long long *hp = (const long long *)ctx->h_pin;
+        for (int f = 0; f < F; f++) {
+            i128 s = 0;
+            if (n > 0)
+                for (int b = 0; b < nblk; b++) s += hp[(size_t)f * nblk + b];
+            lim[2 * f] = (long long)(s >> 32);
+            lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
+        }
+        RSCHK(comm_allreduce_host(ctx, lim, 2 * F, RSSEG_I64, RSSEG_SUM));
+        for (int f = 0; f < F; f++) sums[f] = limbs(lim[2 * f], lim[2 * f + 1]);
+        return RSSEG_OK;
+    };
+    i128 sums[RSSEG_MAX_FEATURES];
+    RSCHK(moment_pass(0, sums));
+    for (int f = 0; f < F; f++) {
+        volatile T s = fixed_to_T<T>(sums[f]);
+        volatile T m = s / Nt;
+        sp.mean[f] = m;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
+    RSCHK(moment_pass(1, sums));
+    T tol;
+    {
+        T var[RSSEG_MAX_FEATURES];
+        for (int f = 0; f < F; f++) {
+            volatile T s = fixed_to_T<T>(sums[f]);
+            volatile T v = s / Nt;
+            var[f] = v;
+        }
+        volatile T m = np_pairwise_sum<T>(var, F);
+        volatile T m2 = m / (T)F;
+        volatile T t = m2 * (T)tol_in;
+        tol = t;
+    }
+    if (info) {
+        for (int f = 0; f < F; f++) {
+            info->scale[f] = (double)sp.scale[f];
+            info->min[f] = (double)sp.minv[f];
+            info->mean[f] = (double)sp.mean[f];
+        }
+        info->tol = (double)tol;
+    }
+
+    // ---- k-means++ (_kmeans.py:213-270) ----
+    mt19937 rng(seed);
+    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+    int64_t init_idx[RSSEG_MAX_CLUSTERS];
+
+    // fetch scaled+centred rows of global pixel indices; every rank ends up with all rows
+    auto fetch_rows = [&](const int64_t *gidx, int cnt, T rows[][RSSEG_MAX_FEATURES]) -> int {
+        double buf[KPP_MAXL * RSSEG_MAX_FEATURES];
+        memset(buf, 0, sizeof(buf));
+        for (int l = 0; l < cnt; l++) {
+            int64_t li = gidx[l] - offset;
+            if (li >= 0 && li < n) {
+                hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li, d_sp, d_row);
+                HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                for (int f = 0; f < F; f++) buf[l * F + f] = (double)((const T *)ctx->h_pin)[f];
+            }
+        }
+        RSCHK(comm_allreduce_host(ctx, buf, (int64_t)cnt * F, RSSEG_F64, RSSEG_SUM));
+        for (int l = 0; l < cnt; l++)
+            for (int f = 0; f < F; f++) rows[l][f] = (T)buf[l * F + f];
+        return RSSEG_OK;
+    };
+    auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt) -> int {
+        T flat[KPP_MAXL * RSSEG_MAX_FEATURES];
+        double cc[KPP_MAXL];
+        for (int l = 0; l < cnt; l++) {
+            double a = 0.0;
+            for (int f = 0; f < F; f++) {
+                flat[l * F + f] = rows[l][f];
+                a = std::fma((double)rows[l][f], (double)rows[l][f], a);
+            }
+            cc[l] = a;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(T) * cnt * F, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_cc, cc, sizeof(double) * cnt, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));  // flat/cc live on this stack frame
+        return RSSEG_OK;
+    };
+    // per-rank totals of the local chunk partials (row `row` of d_part), and the local prefix table
+    std::vector<unsigned long long> h_part((size_t)nchunks * KPP_MAXL);
+    auto pull_partials = [&](int rows) -> int {
+        if (n > 0) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)rows * nchunks, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            memcpy(h_part.data(), ctx->h_pin, sizeof(long long) * (size_t)rows * nchunks);
+        } else {
+            std::fill(h_part.begin(), h_part.end(), 0ull);
+        }
+        return RSSEG_OK;
+    };
+    auto global_total = [&](int row, u128 *rank_tot /*[world]*/, u128 *total) -> int {
+        u128 loc = 0;
+        if (n > 0)
+            for (int64_t c = 0; c < nchunks; c++) loc += h_part[(size_t)row * nchunks + c];
+        long long lim[2 * RSSEG_MAX_RANKS];
+        memset(lim, 0, sizeof(lim));
+        lim[2 * ctx->rank] = (long long)(loc >> 32);
+        lim[2 * ctx->rank + 1] = (long long)(loc & 0xffffffffull);
+        RSCHK(comm_allreduce_host(ctx, lim, 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
+        *total = 0;
+        for (int r = 0; r < ctx->world; r++) {
+            rank_tot[r] = ((u128)(unsigned long long)lim[2 * r] << 32) + (u128)(unsigned long long)lim[2 * r + 1];
+            *total += rank_tot[r];
+        }
+        return RSSEG_OK;
+    };
+
+    {
+        const double u0 = rng.random_sample();
+        init_idx[0] = uniform_choice(N, std::is_same<T, float>::value ? RSSEG_F32 : RSSEG_F64, u0);
+        if (init_idx[0] >= N) init_idx[0] = N - 1;
+        T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
+        RSCHK(fetch_rows(init_idx, 1, rows));
+        for (int f = 0; f < F; f++) C[0][f] = rows[0][f];
+        RSCHK(upload_cands(rows, 1));
+        if (n > 0) {
+            prof_scope ps(ctx, "kpp");
+            hipLaunchKernelGGL((km_kpp<T, 0>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, 1, d_closest,
+                               (unsigned long long *)d_part, nchunks);
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    RSCHK(pull_partials(1));
+    u128 rank_tot[RSSEG_MAX_RANKS], total;
+    RSCHK(global_total(0, rank_tot, &total));
+    T current_pot = (T)((double)total * (1.0 / 1099511627776.0));
+    std::vector<unsigned long long> prefix_part((size_t)nchunks);  // this rank's closest-dist chunk sums
+    for (int64_t c = 0; c < nchunks; c++) prefix_part[c] = h_part[c];
+
+    for (int c = 1; c < k; c++) {
+        int64_t cand_idx[KPP_MAXL];
+        double found[KPP_MAXL];
+        for (int l = 0; l < L; l++) {
+            const double r = rng.random_sample() * (double)current_pot;  // uniform(size=L) * current_pot
+            const long double rl = ceill((long double)r * 1099511627776.0L);
+            const u128 target = rl <= 0 ? (u128)0 : (u128)rl;
+            // owner rank: first rank whose inclusive prefix reaches the target
+            found[l] = 0.0;
+            u128 before = 0;
+            int owner = -1;
+            for (int rk = 0; rk < ctx->world; rk++) {
+                if (n_all[rk] > 0 && before + rank_tot[rk] >= target) { owner = rk; break; }
+                before += rank_tot[rk];
+            }
+            if (owner < 0) {  // beyond the total: np.clip(candidate_ids, None, N-1)
+                if (ctx->rank == 0) found[l] = (double)(N - 1);
+                continue;
+            }
+            if (owner != ctx->rank) continue;
+            u128 run = before;
+            int64_t ch = 0;
+            for (; ch < nchunks; ch++) {
+                if (run + prefix_part[ch] >= target) break;
+                run += prefix_part[ch];
+            }
+            if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
+            const int64_t c0 = ch * CHUNK, cn = std::min<int64_t>(CHUNK, n - c0);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_closest + c0, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const T *hv = (const T *)ctx->h_pin;
+            int64_t li = cn - 1;
+            for (int64_t i = 0; i < cn; i++) {
+                run += (u128)(unsigned long long)llrint((double)hv[i] * 1099511627776.0);
+                if (run >= target) { li = i; break; }
+            }
+            found[l] = (double)(offset + c0 + li);
+        }
+        RSCHK(comm_allreduce_host(ctx, found, L, RSSEG_F64, RSSEG_SUM));
+        for (int l = 0; l < L; l++) cand_idx[l] = (int64_t)found[l];
+        T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
+        RSCHK(fetch_rows(cand_idx, L, rows));
+        RSCHK(upload_cands(rows, L));
+        if (n > 0) {
+            prof_scope ps(ctx, "kpp");
+            hipLaunchKernelGGL((km_kpp<T, 1>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, L, d_closest,
+                               (unsigned long long *)d_part, nchunks);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        RSCHK(pull_partials(L));
+        int best = 0;
+        T best_pot = (T)0;
+        for (int l = 0; l < L; l++) {
+            u128 rt[RSSEG_MAX_RANKS], tot;
+            RSCHK(global_total(l, rt, &tot));
+            T pt = (T)((double)tot * (1.0 / 1099511627776.0));
+            if (l == 0 || pt < best_pot) { best = l; best_pot = pt; }
+        }
+        current_pot = best_pot;
+        for (int f = 0; f < F; f++) C[c][f] = rows[best][f];
+        init_idx[c] = cand_idx[best];
+        // closest = min(closest, d2(best)) and the new prefix table
+        T one[KPP_MAXL][RSSEG_MAX_FEATURES];
+        for (int f = 0; f < F; f++) one[0][f] = rows[best][f];
+        RSCHK(upload_cands(one, 1));
+        if (n > 0) {
+            prof_scope ps(ctx, "kpp");
+            hipLaunchKernelGGL((km_kpp<T, 2>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, 1, d_closest,
+                               (unsigned long long *)d_part, nchunks);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        if (c + 1 < k) {
+            RSCHK(pull_partials(1));
+            RSCHK(global_total(0, rank_tot, &total));
+            for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[cc2];
+        }
+    }
+    if (info)
+        for (int j = 0; j < k; j++) info->init_indices[j] = init_idx[j];
+    const double t_init = now_ms();
+
+    // ---- Lloyd (_kmeans_single_lloyd) ----
+    const size_t lds = sizeof(T) * (size_t)F * TILE + TILE + sizeof(long long) * (size_t)KMAX * F + sizeof(int) * (KMAX + 1) + 64;
+    if (lds > 160 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d needs %zu B of LDS", F, lds);
+    switch (KMAX) {
+    case 8: RSCHK((set_lloyd_attr<T, 8>(ctx, lds))); break;
+    case 16: RSCHK((set_lloyd_attr<T, 16>(ctx, lds))); break;
+    case 32: RSCHK((set_lloyd_attr<T, 32>(ctx, lds))); break;
+    default: RSCHK((set_lloyd_attr<T, 64>(ctx, lds))); break;
+    }
+    auto run_lloyd = [&](bool update) -> int {
+        // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
+        T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS], csq[RSSEG_MAX_CLUSTERS];
+        memset(cenT, 0, sizeof(cenT));
+        memset(csq, 0, sizeof(csq));
+        for (int j = 0; j < k; j++) {
+            T a = (T)0;
+            for (int f = 0; f < F; f++) {
+                cenT[f * KMAX + j] = C[j][f];
+                a = std::is_same<T, float>::value ? (T)fmaf((float)C[j][f], (float)C[j][f], (float)a) : (T)std::fma((double)C[j][f], (double)C[j][f], (double)a);
+            }
+            csq[j] = a;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(d_cen, cenT, sizeof(T) * (size_t)F * KMAX, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_csq, csq, sizeof(T) * KMAX, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (n > 0) {
+            {
+                prof_scope ps(ctx, "lloyd");
+                const size_t l2 = update ? lds : 0;
+                switch (KMAX) {
+                case 8: launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 16: launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 32: launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                default: launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                }
+            }
+            HIPCHK(ctx, hipGetLastError());
+            if (update) {
+                hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, d_part, nchunks, d_red);
+                HIPCHK(ctx, hipGetLastError());
+            }
+        }
+        return RSSEG_OK;
+    };
+
+    if (n > 0) HIPCHK(ctx, hipMemsetAsync(d_lab, 0xFF, (size_t)n, st));
+    bool strict = false;
+    int it = 0, relocated = 0;
+    std::vector<long long> red((size_t)2 * M);
+    for (it = 0; it < max_iter; it++) {
+        RSCHK(run_lloyd(true));
+        if (n > 0) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_red, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            memcpy(red.data(), ctx->h_pin, sizeof(long long) * 2 * M);
+        } else {
+            std::fill(red.begin(), red.end(), 0ll);
+        }
+        RSCHK(comm_allreduce_host(ctx, red.data(), 2 * M, RSSEG_I64, RSSEG_SUM));
+        int64_t cnt[RSSEG_MAX_CLUSTERS];
+        int n_empty = 0;
+        for (int j = 0; j < k; j++) {
+            cnt[j] = (int64_t)limbs(red[2 * (KMAX * F + j)], red[2 * (KMAX * F + j) + 1]);
+            if (cnt[j] == 0) n_empty++;
+        }
+        const int64_t changed = (int64_t)limbs(red[2 * (KMAX * F + KMAX)], red[2 * (KMAX * F + KMAX) + 1]);
+        if (n_empty > 0)
+            return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED,
+                           "kmeans: %d empty cluster(s) at iteration %d — relocation (_relocate_empty_clusters_dense) not implemented yet",
+                           n_empty, it);
+        T Cnew[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+        for (int j = 0; j < k; j++) {
+            volatile T w = (T)cnt[j];
+            volatile T alpha = (T)(1.0 / (double)w);
+            for (int f = 0; f < F; f++) {
+                volatile T s = fixed_to_T<T>(limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]));
+                volatile T cnew = s * alpha;
+                Cnew[j][f] = cnew;
+            }
+        }
+        T shift2[RSSEG_MAX_CLUSTERS];
+        for (int j = 0; j < k; j++) {
+            const T *a = Cnew[j], *b = C[j];
+            volatile T result = (T)0;
+            const int n4 = F / 4, rem = F % 4;
+            for (int g = 0; g < n4; g++) {
+                volatile T d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3];
+                volatile T t0 = d0 * d0, t1 = d1 * d1, t2 = d2 * d2, t3 = d3 * d3;
+                volatile T g1 = t0 + t1;
+                volatile T g2 = g1 + t2;
+                volatile T g4 = g2 + t3;
+                result = result + g4;
+                a += 4;
+                b += 4;
+            }
+            for (int r = 0; r < rem; r++) {
+                volatile T d = a[r] - b[r];
+                volatile T t = d * d;
+                result = result + t;
+            }
+            volatile T sh = std::sqrt((T)result);
+            volatile T s2 = sh * sh;
+            shift2[j] = s2;
+        }
+        memcpy(C, Cnew, sizeof(C));
+        if (changed == 0) {
+            strict = true;
+            it++;
+            break;
+        }
+        const T tot = np_pairwise_sum<T>(shift2, k);
+        if (tot <= tol) {
+            it++;
+            break;
+        }
+    }
+    if (!strict) RSCHK(run_lloyd(false));
+    if (n > 0) {
+        hipLaunchKernelGGL(km_labels_out, dim3((unsigned)std::min<int64_t>(4096, ceil_div64(n, KM_THREADS))), dim3(KM_THREADS), 0, st,
+                           d_lab, d_labels, n);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (centers_out)
+        for (int j = 0; j < k; j++)
+            for (int f = 0; f < F; f++) {
+                volatile T v = C[j][f] + sp.mean[f];  // best_centers += X_mean
+                centers_out[j * F + f] = (double)v;
+            }
+    if (info) {
+        info->n_iter = it;
+        info->relocated = relocated;
+        info->ms_init = t_init - t_start;
+        info->ms_lloyd = now_ms() - t_init;
+    }
+    return RSSEG_OK;
+}
+
+}  // namespace
+
+extern "C" int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k,
+                                        uint32_t seed, int max_iter, double tol, int32_t *d_labels, double *centers,
+                                        rsseg_kmeans_info *info)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_planes || F < 1 || F > RSSEG_MAX_FEATURES) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: F=%d outside [1,%d]", F, RSSEG_MAX_FEATURES);
+    if (k < 1 || k > RSSEG_MAX_CLUSTERS) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_clusters=%d outside [1,%d]", k, RSSEG_MAX_CLUSTERS);
+    if (n_local < 0 || (n_local > 0 && !d_labels)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: bad n_local / labels");
+    if (max_iter < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: max_iter must be >= 1");
+    if (dtype != RSSEG_F32 && dtype != RSSEG_F64) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: dtype must be RSSEG_F32 or RSSEG_F64");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (info) memset(info, 0, sizeof(*info));
+    if (dtype == RSSEG_F32) return kmeans_fit<float>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info);
+    return kmeans_fit<double>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info);
+}
+
+// host-only helper (no GPU): the draws sklearn takes from RandomState(seed) for k-means++ on n samples.
+// Exposed so the CPU test-suite can check the MT19937 / cumulative-probability restatement against NumPy.
+extern "C" int rsseg_host_kmeans_draws(uint32_t seed, int64_t n, int dtype, int k, int64_t *center_id, double *uniforms)
+{
+    if (n < 1 || k < 1 || !center_id) return RSSEG_ERR_INVALID;
+    mt19937 rng(seed);
+    *center_id = uniform_choice(n, dtype, rng.random_sample());
+    const int L = 2 + (int)std::log((double)k);
+    if (uniforms)
+        for (int i = 0; i < (k - 1) * L; i++) uniforms[i] = rng.random_sample();
+    return RSSEG_OK;
+}

@@ -1,0 +1,284 @@
+"""
+Host runtime over the C ABI: one Context per process / GPU.
+
+torch-ROCm is used for three things only: device allocations (tensors as buffers, `.data_ptr()`
+handed to the library), the current HIP stream, and `torch.distributed` (backend "nccl" = RCCL over
+xGMI) behind the library's all-reduce hook.  All arithmetic on rasters happens in librsseg_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+class RssegError(RuntimeError):
+    pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Context:
+    """Owns an rsseg_ctx.  `group` (optional) is a torch.distributed process group: when its world
+    size is > 1 the library's reductions go through RCCL (or gloo in CPU tests of the hook)."""
+
+    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None):
+        torch = _torch()
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RssegError("no GPU visible to torch: the rsseg product path needs an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.rsseg_ctx_create(device, C.c_void_p(stream), C.byref(h))
+        if rc != 0:
+            raise RssegError(f"rsseg_ctx_create failed ({rc}): {self.lib.rsseg_last_error(None).decode()}")
+        self.h = h
+        self.rank, self.world = 0, 1
+        self._comm_buf = None
+        self._hook = None
+        import torch.distributed as dist
+        if use_dist is None:
+            use_dist = dist.is_available() and dist.is_initialized()
+        if use_dist and dist.get_world_size(group) > 1:
+            self._install_comm(group)
+
+    # ---- communication hook ----------------------------------------------------------------
+    def _install_comm(self, group):
+        torch = _torch()
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._comm_buf = torch.zeros(1 << 21, dtype=torch.uint8, device=self.device)
+        views = {L.F32: torch.float32, L.F64: torch.float64, L.I64: torch.int64}
+        ops = {L.SUM: dist.ReduceOp.SUM, L.MIN: dist.ReduceOp.MIN, L.MAX: dist.ReduceOp.MAX}
+        buf = self._comm_buf
+
+        def hook(_user, offset, count, dtype, op):
+            try:
+                dt = views[dtype]
+                esz = 4 if dtype == L.F32 else 8
+                t = buf[offset:offset + count * esz].view(dt)
+                dist.all_reduce(t, op=ops[op], group=group)
+                torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception as e:  # noqa: BLE001 — must not propagate through the C frame
+                print(f"[rsseg] all-reduce hook failed: {e!r}", flush=True)
+                return 1
+
+        self._hook = L.ALLREDUCE_FN(hook)
+        self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
+                                              C.c_void_p(buf.data_ptr()), buf.numel()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rsseg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = self.lib.rsseg_last_error(self.h).decode(errors="replace")
+            if rc == -1:
+                raise ValueError(msg)
+            if rc == -3:
+                raise MemoryError(msg)
+            raise RssegError(f"rsseg error {rc}: {msg}")
+
+    # ---- buffers --------------------------------------------------------------------------------
+    def to_device(self, a: np.ndarray, dtype=None):
+        torch = _torch()
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return torch.from_numpy(a).to(self.device)
+
+    def empty(self, n, dtype):
+        torch = _torch()
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _pp(tensors: Sequence) -> "C.Array":
+        arr = (C.c_void_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = None if t is None else t.data_ptr()
+        return arr
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._chk(self.lib.rsseg_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.lib.rsseg_prof_reset(self.h))
+
+    def prof_get(self, name: str) -> Tuple[float, int]:
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._chk(self.lib.rsseg_prof_get(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    # ---- K1 ------------------------------------------------------------------------------------
+    def order_stats(self, plane, ranks: Sequence[int]) -> Tuple[np.ndarray, int]:
+        r = (C.c_int64 * len(ranks))(*[int(x) for x in ranks])
+        out = (C.c_float * len(ranks))()
+        nn = C.c_int64(0)
+        self._chk(self.lib.rsseg_order_stats_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), r, len(ranks), out,
+                                                 C.byref(nn)))
+        return np.array(out[:], dtype=np.float32), nn.value
+
+    # ---- K2 ------------------------------------------------------------------------------------
+    def normalize(self, plane, lo: float, hi: float, out=None):
+        out = self.empty(plane.numel(), plane.dtype) if out is None else out
+        self._chk(self.lib.rsseg_normalize_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo),
+                                               C.c_float(hi), C.c_void_p(out.data_ptr())))
+        return out
+
+    def spectral_indices(self, bands5: Sequence, lohi: Optional[np.ndarray], want_norm: Sequence[bool] = (False,) * 5,
+                         want: Sequence[bool] = (True,) * 7):
+        torch = _torch()
+        n = bands5[0].numel()
+        outs = [self.empty(n, torch.float32) if w else None for w in want]
+        norms = [self.empty(n, torch.float32) if w else None for w in want_norm]
+        lh = None
+        if lohi is not None:
+            lh = (C.c_float * 10)(*[float(v) for v in np.asarray(lohi, np.float32).reshape(-1)])
+        self._chk(self.lib.rsseg_spectral_indices_f32(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms)))
+        return outs, norms
+
+    def quantize_u8(self, plane, mult: float):
+        torch = _torch()
+        q = self.empty(plane.numel(), torch.uint8)
+        self._chk(self.lib.rsseg_quantize_u8(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(mult),
+                                             C.c_void_p(q.data_ptr())))
+        return q
+
+    # ---- K3 ------------------------------------------------------------------------------------
+    def pca_fit_transform(self, bands: Sequence, center: Optional[np.ndarray], scale: Optional[np.ndarray],
+                          n_components: int):
+        torch = _torch()
+        nb, n = len(bands), bands[0].numel()
+        outs = [self.empty(n, torch.float32) for _ in range(n_components)]
+        comp = np.zeros((n_components, nb), np.float32)
+        ratio = np.zeros(n_components, np.float32)
+        mean = np.zeros(nb, np.float32)
+        ev = np.zeros(n_components, np.float32)
+        fp = C.POINTER(C.c_float)
+        cptr = None if center is None else np.ascontiguousarray(center, np.float32).ctypes.data_as(fp)
+        sc64 = None if scale is None else np.ascontiguousarray(scale, np.float64)
+        sptr = None if sc64 is None else sc64.ctypes.data_as(C.POINTER(C.c_double))
+        self._chk(self.lib.rsseg_pca_fit_transform_f32(self.h, self._pp(bands), nb, n, cptr, sptr, n_components,
+                                                       self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
+                                                       mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        return outs, comp, ratio, mean, ev
+
+    # ---- K4..K8 --------------------------------------------------------------------------------
+    def glcm(self, q, H: int, W: int, levels: int, win: int, step: int):
+        torch = _torch()
+        oh, ow = (H - win) // step + 1, (W - win) // step + 1
+        outs = [self.empty(oh * ow, torch.float32) for _ in range(5)]
+        self._chk(self.lib.rsseg_glcm_u8(self.h, C.c_void_p(q.data_ptr()), H, W, levels, win, step, self._pp(outs)))
+        return outs, (oh, ow)
+
+    def resize_bilinear(self, src, sh: int, sw: int, dh: int, dw: int):
+        torch = _torch()
+        dst = self.empty(dh * dw, torch.float32)
+        self._chk(self.lib.rsseg_resize_bilinear_f32(self.h, C.c_void_p(src.data_ptr()), sh, sw, C.c_void_p(dst.data_ptr()),
+                                                     dh, dw))
+        return dst
+
+    def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False):
+        torch = _torch()
+        out = self.empty(H * W, torch.float32)
+        self._chk(self.lib.rsseg_box_mean_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, border, int(square),
+                                              C.c_void_p(out.data_ptr())))
+        return out
+
+    def local_std(self, plane, H: int, W: int, k: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.float32)
+        self._chk(self.lib.rsseg_local_std_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
+        return out
+
+    def morph_gradient(self, q, H: int, W: int, k: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_morph_gradient_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
+        return out
+
+    def sobel_mag(self, q, H: int, W: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.float32)
+        self._chk(self.lib.rsseg_sobel_mag_u8(self.h, C.c_void_p(q.data_ptr()), H, W, C.c_void_p(out.data_ptr())))
+        return out
+
+    # ---- K9/K10 --------------------------------------------------------------------------------
+    def kmeans_fit_predict(self, planes: Sequence, n_clusters: int, seed: int = 42, max_iter: int = 300, tol: float = 1e-4):
+        torch = _torch()
+        F, n = len(planes), planes[0].numel()
+        dt = planes[0].dtype
+        if any(p.dtype != dt for p in planes) or dt not in (torch.float32, torch.float64):
+            raise ValueError("kmeans planes must all be float32 or all float64")
+        labels = self.empty(max(n, 1), torch.int32)
+        centers = np.zeros((n_clusters, F), np.float64)
+        info = L.KMeansInfo()
+        self._chk(self.lib.rsseg_kmeans_fit_predict(self.h, self._pp(planes), F, L.F32 if dt == torch.float32 else L.F64, n,
+                                                    n_clusters, seed, max_iter, tol, C.c_void_p(labels.data_ptr()),
+                                                    centers.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info)))
+        meta = dict(n_iter=info.n_iter, tol=info.tol, relocated=info.relocated,
+                    scale=np.array(info.scale[:F]), min=np.array(info.min[:F]), mean=np.array(info.mean[:F]),
+                    init_indices=np.array(info.init_indices[:n_clusters]), ms_init=info.ms_init, ms_lloyd=info.ms_lloyd,
+                    centers=centers)
+        return labels[:n], meta
+
+    # ---- K11 -----------------------------------------------------------------------------------
+    def forest_load(self, forest: dict):
+        f = forest
+        ip, lp, dp = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        keep = [np.ascontiguousarray(f["tree_off"], np.int64), np.ascontiguousarray(f["left"], np.int32),
+                np.ascontiguousarray(f["right"], np.int32), np.ascontiguousarray(f["feature"], np.int32),
+                np.ascontiguousarray(f["threshold"], np.float64), np.ascontiguousarray(f["missing_left"], np.uint8),
+                np.ascontiguousarray(f["value"], np.float64), np.ascontiguousarray(f["classes"], np.int64)]
+        self._chk(self.lib.rsseg_forest_load(self.h, len(keep[0]) - 1, keep[0].ctypes.data_as(lp), keep[1].ctypes.data_as(ip),
+                                             keep[2].ctypes.data_as(ip), keep[3].ctypes.data_as(ip), keep[4].ctypes.data_as(dp),
+                                             keep[5].ctypes.data_as(C.POINTER(C.c_uint8)), keep[6].ctypes.data_as(dp),
+                                             keep[6].shape[1], keep[7].ctypes.data_as(lp), int(f["n_features"])))
+
+    def forest_predict(self, planes: Sequence):
+        torch = _torch()
+        n = planes[0].numel()
+        out = self.empty(n, torch.int64)
+        self._chk(self.lib.rsseg_forest_predict(self.h, self._pp(planes), len(planes), n, C.c_void_p(out.data_ptr())))
+        return out
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on LOCAL_RANK (or device 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx
+
+
+def host_kmeans_draws(n: int, k: int, dtype, seed: int = 42) -> Tuple[int, np.ndarray]:
+    """CPU-only: the k-means++ random draws as the library computes them (for tests)."""
+    lib = L.load()
+    Lt = 2 + int(np.log(k))
+    u = np.zeros(max((k - 1) * Lt, 1), np.float64)
+    cid = C.c_int64(0)
+    rc = lib.rsseg_host_kmeans_draws(seed, n, L.F32 if np.dtype(dtype) == np.float32 else L.F64, k, C.byref(cid),
+                                     u.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise ValueError("rsseg_host_kmeans_draws failed")
+    return cid.value, u[:(k - 1) * Lt]

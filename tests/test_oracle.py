@@ -1,0 +1,152 @@
+"""CPU suite, part 1: the oracle restatement against the golden vectors produced by the reference
+itself (oracle/gen_golden.py) and against the reference's committed artefacts."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+KEYS = ["ndvi", "evi", "msavi", "ndwi", "mndwi", "ndbi", "bsi"]
+
+
+@pytest.fixture(scope="module")
+def crop(golden_dir):
+    return np.load(os.path.join(golden_dir, "crop96.npz"))
+
+
+@pytest.fixture(scope="module")
+def scene(golden_dir):
+    return np.load(os.path.join(golden_dir, "scene_aa.npz"))
+
+
+def _indices(O, norm):
+    b, g, r, n, s = norm[:5]
+    return {"ndvi": O.calculate_ndvi(n, r), "evi": O.calculate_evi(n, r, b), "msavi": O.calculate_msavi(n, r),
+            "ndwi": O.calculate_ndwi(g, n), "mndwi": O.calculate_mndwi(g, s), "ndbi": O.calculate_ndbi(s, n),
+            "bsi": O.calculate_bsi(b, r, n, s)}
+
+
+def test_normalize_and_indices_bitexact(oracle, crop):
+    norm = [oracle.robust_normalize(b) for b in crop["bands"]]
+    for a, b in zip(norm, crop["norm"]):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    idx = _indices(oracle, norm)
+    for k in KEYS:
+        assert idx[k].dtype == np.float32
+        assert np.array_equal(idx[k], crop["idx_" + k]), k
+
+
+def test_indices_nan_and_zero_denominator(oracle):
+    a = np.array([[0.0, 0.0005, np.nan, 0.3]], np.float32)
+    b = np.array([[0.0, 0.0004, 0.2, np.nan]], np.float32)
+    out = oracle.calculate_ndvi(a, b)
+    assert np.array_equal(out, np.zeros_like(out))  # den <= 0.001 or NaN -> 0
+
+
+def test_pca_matches_reference(oracle, crop):
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):
+        pcs, ratio, model = oracle.perform_pca(list(crop["norm"]))
+        pcs3, ratio3, _ = oracle.perform_pca(list(crop["norm"]), n_components=3)
+    assert np.allclose(np.stack(pcs), crop["pca7"], rtol=0, atol=1e-5)
+    assert np.allclose(ratio, crop["pca7_ratio"], atol=1e-6)
+    assert np.allclose(np.stack(pcs3), crop["pca3"], rtol=0, atol=1e-5)
+    assert np.allclose(model["components"], crop["pca7_components"], atol=1e-5)
+
+
+@pytest.mark.parametrize("k", [6, 7, 8])
+def test_kmeans_idx7_labels_equal_sklearn(oracle, crop, k):
+    planes = [crop["idx_" + n] for n in KEYS]
+    labels, info = oracle.kmeans_fit_planes(planes, k)
+    assert labels.dtype == np.int32
+    assert np.array_equal(labels, crop[f"kmeans_idx7_k{k}"].reshape(-1))
+    assert info["relocated"] == 0
+
+
+@pytest.mark.parametrize("k", [6, 8])
+def test_kmeans_stack19_f64_labels_equal_sklearn(oracle, crop, k):
+    st = crop["stack19"]
+    assert st.dtype == np.float64
+    labels, _ = oracle.kmeans_fit_planes([st[:, :, i] for i in range(19)], k)
+    assert np.array_equal(labels, crop[f"kmeans_stack19_k{k}"].reshape(-1))
+
+
+def test_kmeans_nan_replaced_by_zero(oracle, crop):
+    planes = [crop["idx_" + n] for n in KEYS]
+    planes[0] = crop["kmeans_idx7_nan_input"]
+    labels, _ = oracle.kmeans_fit_planes(planes, 6)
+    assert np.array_equal(labels, crop["kmeans_idx7_nan_k6"].reshape(-1))
+
+
+def test_kmeans_full_scene_vs_sklearn_near_ties_only(oracle, scene, golden_dir):
+    """On the 600x600 scene sklearn's own float32 accumulation order moves ~1e-4 of the labels
+    (SURVEY.md §7); every disagreement must be a near-tie between the two centres involved."""
+    ref = np.load(os.path.join(golden_dir, "scene_aa_ref_outputs.npz"))
+    bands = oracle.stage1_preprocess(scene["dn"])
+    norm = [oracle.robust_normalize(b) for b in bands]
+    idx = _indices(oracle, norm)
+    planes = [idx[n] for n in KEYS]
+    for k in (6,):
+        labels, info = oracle.kmeans_fit_planes(planes, k)
+        refl = ref[f"kmeans_idx7_k{k}"].reshape(-1).astype(np.int32)
+        bad = np.nonzero(labels != refl)[0]
+        assert bad.size <= 2e-4 * labels.size
+        X = np.stack([p.reshape(-1) for p in planes], 1).astype(np.float64)
+        Xs = X * info["scale"] + info["min"] - info["mean"]  # centres are in the centred space
+        C = info["centers"]
+        d = ((Xs[bad, None, :] - C[None, :, :]) ** 2).sum(-1)
+        gap = np.abs(d[np.arange(bad.size), labels[bad]] - d[np.arange(bad.size), refl[bad]])
+        assert gap.max() < 2e-3, gap.max()
+
+
+def test_percentiles_match_reference(oracle, scene, golden_dir):
+    ref = np.load(os.path.join(golden_dir, "scene_aa_ref_outputs.npz"))
+    bands = oracle.stage1_preprocess(scene["dn"])
+    got = np.array([[np.percentile(b, 2), np.percentile(b, 98)] for b in bands], np.float32)
+    assert np.array_equal(got, ref["percentiles_2_98"])
+
+
+def test_rf_walk_matches_sklearn(oracle, crop, golden_dir):
+    f = dict(np.load(os.path.join(golden_dir, "rf_samples_model_flat.npz")))
+    X = crop["rf_X"]
+    out = oracle.rf_predict_planes(f, [X[:, i] for i in range(19)])
+    assert np.array_equal(out, crop["rf_pred_image"].reshape(-1))
+    Xn = crop["rf_X_nan"]
+    out = oracle.rf_predict_planes(f, [Xn[:, i] for i in range(19)])
+    assert np.array_equal(out, crop["rf_pred_nan_native"].reshape(-1))
+    out0 = oracle.rf_predict_planes(f, [np.nan_to_num(Xn[:, i], nan=0.0) for i in range(19)])
+    assert np.array_equal(out0, crop["rf_pred_nan_zeroed"].reshape(-1))
+
+
+def test_glcm_pair_form_equals_literal_form(oracle):
+    rng = np.random.default_rng(7)
+    q = rng.integers(0, 32, (40, 45)).astype(np.uint8)
+    q[:10, :10] = 5  # constant windows: correlation = 1 branch
+    for win, step in ((7, 1), (7, 7), (21, 21), (5, 3)):
+        a = oracle.glcm_small_maps(q, 32, win, step, mode=0)
+        b = oracle.glcm_small_maps(q, 32, win, step, mode=1)
+        for k in a:
+            assert np.allclose(a[k], b[k], rtol=1e-6, atol=1e-7), (k, win, step)
+
+
+def test_class_map_end_to_end(oracle, scene, golden_dir):
+    """The reference's committed output/class_map.npy = bundled forest applied to the 19-feature stack
+    of the bundled scene: pins every feature stage (cv2 / skimage restatements included) and the walk."""
+    f = dict(np.load(os.path.join(golden_dir, "rf_samples_model_flat.npz")))
+    bands = oracle.stage1_preprocess(scene["dn"])
+    _, hier = oracle.run_feature_extraction_stage(bands)
+    assert hier["all"].shape == (600, 600, 19) and hier["all"].dtype == np.float64
+    cm = oracle.predict_image(f, hier["all"])
+    assert cm.dtype == np.int64
+    agree = float(np.mean(cm == scene["class_map"]))
+    assert agree >= 0.999, agree
+    for (x, y), lab in zip(scene["sample_coords"], scene["sample_labels"]):
+        assert cm[y, x] == lab
+        assert scene["roi_mask"][y, x] == lab
+
+
+def test_pin_report_is_committed(golden_dir):
+    rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))
+    assert rep["class_map_agreement"] >= 0.999
+    assert rep["rf_mismatch"] == 0 and rep["robust_normalize_bitexact"]
+    assert all(rep["indices_bitexact"].values())
