@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""
+bench.py — Mpixel/s of feature-extract + classify on a device-resident 7-band raster (BASELINE.json).
+
+One "step" = one pass of the hot path over the raster already resident in HBM:
+  config c3 (default, BASELINE configs[2], the configuration the metric is quoted on):
+      percentile normalisation of 7 bands -> 7 spectral indices -> RobustScaler + PCA(3) ->
+      GLCM (7x7 window, step 1, 32 levels, 4 angles, 5 properties, bilinear back to H x W) ->
+      15 float32 features -> MinMax + KMeans(k=8, k-means++, random_state=42) -> int32 label plane
+  config c2 (BASELINE configs[1]): 7 indices -> KMeans(k=6) on a 4096 x 4096 raster.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank holds one H x W tile
+of an (N*H) x W scene (weak scaling); histograms, PCA sums and KMeans partials go through RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "rs-image-segmentation_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def synth_tile(torch, device, H, W, row0, bands=7, stripe=2048):
+    """SURVEY.md §8(d) generator, evaluated on the device: 8 spectral prototypes on a 64-px checkerboard
+    + N(0, 6) noise, clipped, truncated to uint8, stored as float32 (integer-valued DN like the real
+    preprocessed tile).  Deterministic in the global row position."""
+    proto = torch.tensor(np.random.default_rng(355).integers(20, 230, (8, bands)), dtype=torch.float32, device=device)
+    out = [torch.empty(H * W, dtype=torch.float32, device=device) for _ in range(bands)]
+    x = torch.arange(W, device=device)[None, :]
+    for r0 in range(0, H, stripe):
+        rows = min(stripe, H - r0)
+        g = torch.Generator(device=device)
+        g.manual_seed(355_000 + (row0 + r0) // stripe)
+        y = (torch.arange(rows, device=device) + (row0 + r0))[:, None]
+        lab = ((y // 64) * 7 + (x // 64) * 3) % 8
+        for b in range(bands):
+            v = proto[lab, b] + torch.randn(rows, W, generator=g, device=device) * 6.0
+            out[b][r0 * W:(r0 + rows) * W] = v.clamp_(0, 255).to(torch.uint8).to(torch.float32).reshape(-1)
+    return out
+
+
+# algorithmic HBM bytes per pixel and launch of each kernel family
+def algorithmic_bytes_per_px(family, F, glcm_step):
+    return {
+        "glcm": 4 + 20.0 / (glcm_step * glcm_step),   # read plane once, write 5 property maps
+        "lloyd": 4 * F + 8,                            # F float32 features + label read/write
+        "kpp": 4 * F + 8,                              # F features + closest-distance read/write
+        "select": 4,                                   # one radix pass over one float32 plane
+        "indices": 20 + 28,                            # 5 bands in, 7 indices out
+        "gram": 28, "project": 28 + 12, "resize": 8, "box": 8, "stencil": 8, "forest": 4 * F + 8,
+    }[family]
+
+
+def cpu_baseline(O, tile_bands, H, W, crop, cfg, k):
+    """Oracle ("port", single thread) on a crop of the same raster; returns (Mpx/s, description)."""
+    from threadpoolctl import threadpool_limits
+    c = min(crop, H, W)
+    b = [t.reshape(H, W)[:c, :c].cpu().numpy().copy() for t in tile_bands]
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=1):
+        norm = [O.robust_normalize(x) for x in b]
+        bl, g, r, n, s = norm[:5]
+        feats = [O.calculate_ndvi(n, r), O.calculate_evi(n, r, bl), O.calculate_msavi(n, r), O.calculate_ndwi(g, n),
+                 O.calculate_mndwi(g, s), O.calculate_ndbi(s, n), O.calculate_bsi(bl, r, n, s)]
+        if cfg == "c3":
+            pcs, _, _ = O.perform_pca(norm, n_components=3)
+            gl, _ = O.calculate_glcm_features(norm[3], 32, 7, 1)
+            feats = feats + [gl[x] for x in ("contrast", "dissimilarity", "homogeneity", "energy", "correlation")] + list(pcs)
+        O.kmeans_fit_planes(feats, k)
+    dt = time.perf_counter() - t0
+    return (c * c / 1e6) / dt, f"{c}x{c}x7 crop of the same synthetic raster, full {cfg} path, oracle C/NumPy port, 1 thread, {dt:.1f} s"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--size", type=int, default=0, help="tile edge (default 16384 for c3, 4096 for c2)")
+    ap.add_argument("--glcm-step", type=int, default=1)
+    ap.add_argument("--cpu-crop", type=int, default=768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    from rsseg import pipeline as P
+    from rsseg.runtime import Context
+    ctx = Context(local)
+
+    H = W = args.size or (16384 if args.config == "c3" else 4096)
+    k = 8 if args.config == "c3" else 6
+    F = 15 if args.config == "c3" else 7
+    n_global = H * W * world
+    bands = synth_tile(torch, device, H, W, rank * H)
+    torch.cuda.synchronize()
+
+    def step():
+        if args.config == "c3":
+            return run_c3(ctx, P, bands, H, W, k, args.glcm_step, n_global)
+        return run_c2(ctx, P, bands, k, n_global)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    meta = None
+    for _ in range(args.warmup):
+        labels, meta = step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        labels, meta = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fams = {}
+    for fam in ("glcm", "lloyd", "kpp", "select", "indices", "gram", "project", "resize"):
+        ms, cnt = ctx.prof_get(fam)
+        if cnt:
+            fams[fam] = (ms, cnt)
+    ctx.prof_enable(False)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n_global / 1e6 / (dt / args.steps)
+        dom = max(fams, key=lambda f: fams[f][0]) if fams else None
+        roof = None
+        if dom:
+            ms, cnt = fams[dom]
+            per_launch_s = ms / cnt / 1e3
+            px = H * W if dom != "glcm" else ((H - 7) // args.glcm_step + 1) * ((W - 7) // args.glcm_step + 1)
+            bpp = algorithmic_bytes_per_px(dom, F, args.glcm_step)
+            achieved = px * bpp / per_launch_s / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": cnt / args.steps,
+                    "family_ms_per_step": {f: round(v[0] / args.steps, 3) for f, v in fams.items()}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_np as O
+            v, desc = cpu_baseline(O, bands, H, W, args.cpu_crop, args.config, k)
+            cpu = {"value": round(v, 4), "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": desc}
+        out = {
+            "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{H}x{W}x7 synthetic TM tile per GPU, robust-normalise + 7 spectral indices"
+                                    + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if args.config == "c3" else "")
+                                    + f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)"),
+                       "tile": [H, W, 7], "n_features": F, "n_clusters": k, "kmeans_n_iter": int(meta["n_iter"]),
+                       "parallelism": f"tile-sharded x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_c2(ctx, P, bands, k, n_global):
+    lohi = P.band_lohi(ctx, bands[:5], n_global)
+    idx, _ = P.spectral_indices(ctx, bands, lohi)
+    planes = [idx[n] for n in P.INDEX_NAMES]
+    return ctx.kmeans_fit_predict(planes, k)
+
+
+def run_c3(ctx, P, bands, H, W, k, glcm_step, n_global):
+    lohi = P.band_lohi(ctx, bands, n_global)
+    idx, norms = P.spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+    norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+    pcs, _, _ = P.pca(ctx, norm_all, 3, True, n_global)
+    nir2 = P.renormalize(ctx, norm_all[3], n_global)
+    del norm_all, norms
+    glcm, _ = P.glcm_features(ctx, nir2, H, W, 32, 7, glcm_step)
+    planes = [idx[n] for n in P.INDEX_NAMES] + [glcm[n] for n in P.GLCM_NAMES] + list(pcs)
+    return ctx.kmeans_fit_predict(planes, k)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,8 +96,14 @@ template <int WIN, int A> struct angle_geom {
 };
 
 // pair statistics of one angle; key = diag<<16 | lo<<8 | hi, sorted, equal runs counted
+// window rows packed 4 pixels per register: w[r][0] = px 0..3, w[r][1] = px 4..7
+template <int R, int C> __device__ __forceinline__ int px_at(const unsigned (&w)[8][2])
+{
+    return (int)((w[R][C >> 2] >> (8 * (C & 3))) & 0xffu);
+}
+
 template <int WIN, int A>
-__device__ __forceinline__ void glcm_angle(const int (&v)[WIN][WIN], const long long *__restrict__ hq, glcm_stats &s)
+__device__ __forceinline__ void glcm_angle(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_stats &s)
 {
     using G = angle_geom<WIN, A>;
     constexpr int P = G::P;
@@ -108,7 +114,7 @@ __device__ __forceinline__ void glcm_angle(const int (&v)[WIN][WIN], const long 
     static_for<P>([&](auto I) {
         constexpr int p = I;
         constexpr int r = p / G::PW, c = G::C0 + p % G::PW;
-        const int x = v[r][c], y = v[r + G::DR][c + G::DC];
+        const int x = px_at<r, c>(w), y = px_at<r + G::DR, c + G::DC>(w);
         const int lo = x < y ? x : y, hi = x < y ? y : x;
         const unsigned d = (unsigned)(hi - lo);
         key[p] = ((d == 0 ? 1u : 0u) << 16) | ((unsigned)lo << 8) | (unsigned)hi;
@@ -117,6 +123,9 @@ __device__ __forceinline__ void glcm_angle(const int (&v)[WIN][WIN], const long 
         M1 += x + y;
         M2 += x * x + y * y;
         Mx += 2 * x * y;
+        // keep at most 8 LUT reads in flight: unconstrained, the scheduler issues all P of them up front
+        // and their 2P result registers push the kernel to one wave per SIMD
+        if constexpr (p % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     });
     static_for<net_holder<P>::net.n>([&](auto I) {
         constexpr int ia = net_holder<P>::net.a[I], ib = net_holder<P>::net.b[I];
@@ -143,14 +152,15 @@ __device__ __forceinline__ void glcm_angle(const int (&v)[WIN][WIN], const long 
     s.A = 2ll * (P + (int)D) + 4ll * (long long)E2;
 }
 
-// compiler fence between angles: stops common sub-expressions of different angles from being hoisted
-// together (their combined live ranges do not fit the register file)
-template <int WIN> __device__ __forceinline__ void opaque_window(int (&v)[WIN][WIN])
+// compiler fence: the packed window is redefined (as far as the compiler can tell) at the top of every
+// angle iteration, so the four angle bodies cannot be hoisted out of the loop or merged
+template <int WIN> __device__ __forceinline__ void opaque_window(unsigned (&w)[8][2])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_for<WIN * WIN>([&](auto I) {
-        int &ref = v[I / WIN][I % WIN];
-        asm volatile("" : "+v"(ref));
+    static_for<WIN>([&](auto I) {
+        unsigned &a = w[I][0];
+        unsigned &b = w[I][1];
+        asm volatile("" : "+v"(a), "+v"(b));
     });
 #endif
 }
@@ -165,43 +175,38 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= ow || oy >= oh) return;
-    int v[WIN][WIN];
+    unsigned w[8][2];
     {
         const uint8_t *wp = q + (size_t)(oy * step) * W + (size_t)ox * step;
-        static_for<WIN * WIN>([&](auto I) {
-            constexpr int r = I / WIN, c = I % WIN;
-            v[r][c] = wp[(size_t)r * W + c];
+        static_for<WIN>([&](auto I) {
+            constexpr int r = I;
+            unsigned lo = 0, hi = 0;
+            static_for<WIN>([&](auto J) {
+                constexpr int c = J;
+                const unsigned b = wp[(size_t)r * W + c];
+                if constexpr (c < 4) lo |= b << (8 * c);
+                else hi |= b << (8 * (c - 4));
+            });
+            w[r][0] = lo;
+            w[r][1] = hi;
         });
     }
-    // angles strictly one after the other: each needs ~P key registers, overlapping them spills
-    double sc, sd, sh, se, sr;
-    {
+    // The four angles run through a RUNTIME loop on purpose: unrolled, the compiler merges their common
+    // sub-expressions and the combined live ranges (4 x ~42 keys + 49 pixels) spill to scratch.
+    double sc = 0, sd = 0, sh = 0, se = 0, sr = 0;
+#pragma nounroll
+    for (int a = 0; a < 4; a++) {
+        opaque_window<WIN>(w);  // the angle bodies are loop-invariant: without this they are all hoisted
         glcm_stats s;
-        glcm_angle<WIN, 0>(v, hq, s);
-        glcm_props(s, sc, sd, sh, se, sr);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        glcm_stats s;
+        switch (a) {
+        case 0: glcm_angle<WIN, 0>(w, hq, s); break;
+        case 1: glcm_angle<WIN, 1>(w, hq, s); break;
+        case 2: glcm_angle<WIN, 2>(w, hq, s); break;
+        default: glcm_angle<WIN, 3>(w, hq, s); break;
+        }
         double c, d, h, e, r;
-        glcm_angle<WIN, 1>(v, hq, s);
         glcm_props(s, c, d, h, e, r);
-        sc = sc + c; sd = sd + d; sh = sh + h; se = se + e; sr = sr + r;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        glcm_stats s;
-        double c, d, h, e, r;
-        glcm_angle<WIN, 2>(v, hq, s);
-        glcm_props(s, c, d, h, e, r);
-        sc = sc + c; sd = sd + d; sh = sh + h; se = se + e; sr = sr + r;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        glcm_stats s;
-        double c, d, h, e, r;
-        glcm_angle<WIN, 3>(v, hq, s);
-        glcm_props(s, c, d, h, e, r);
+        // (((p0 + p1) + p2) + p3): adding to an exact 0.0 first does not change p0
         sc = sc + c; sd = sd + d; sh = sh + h; se = se + e; sr = sr + r;
     }
     const size_t o = (size_t)oy * ow + ox;

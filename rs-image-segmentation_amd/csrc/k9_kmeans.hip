@@ -256,9 +256,29 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
 // cenT: [F][KMAX] centres (transposed so one scalar load brings the KMAX values of a feature),
 // csq: [KMAX].  labels: uint8 per pixel.  partial (UPDATE only): [(KMAX*F + KMAX + 1)][nchunks]
 // int64: per-cluster fixed-point sums, per-cluster counts, number of changed labels.
-// LDS: tile[F][TILE] of scaled+centred values + per-wave scratch.
+//
+// One workgroup walks one chunk (16 tiles).  Per tile each lane owns PXL consecutive pixels:
+//   load     all F feature vectors of the lane's pixels are requested back to back (F x 16 B per
+//            lane in flight: a wave keeps F KiB of HBM reads outstanding, which is what hides the
+//            latency at the 3 workgroups per CU the register budget allows) and stay in REGISTERS
+//            for the whole tile — the per-cluster accumulation needs them again after the argmin;
+//   phase A  scale/centre, accumulate the k dot products (fma chain over f, as sklearn's gemm);
+//   argmin   strict '<' (lowest index wins), label written as uint8;
+//   phase B  the 2^-40 fixed-point images of the lane's values are added to per-cluster 64-bit LDS
+//            accumulators.  The accumulators are replicated 32 times (copy = lane & 31, copy stride
+//            = 2 banks mod 64) so that the 64 lanes of a ds_add_u64 never collide on a bank when
+//            they carry the same label — the common case, labels being spatially coherent.
+//            Integer adds commute, so the result is independent of any order.
+// LDS: 32 accumulator copies only (33 KB at KMAX = 8, F <= 15).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KMAX, bool UPDATE>
+#define KM_COPIES 32
+__host__ __device__ inline int km_copy_stride(int KMAX, int F)
+{
+    // in 8-byte words; an odd stride puts copy c on banks {2c, 2c+1} (mod 64)
+    return (KMAX * F + KMAX) | 1;
+}
+
+template <typename T, int KMAX, int FR, bool UPDATE>
 __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k, int64_t n,
                                                        const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
                                                        const T *__restrict__ csq, uint8_t *__restrict__ labels,
@@ -267,16 +287,13 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
     constexpr int PXL = vt<T>::PXL;
     constexpr int TILE = KM_THREADS * PXL;
     extern __shared__ __align__(16) char smem[];
-    T *tile = reinterpret_cast<T *>(smem);                                   // [F][TILE]
-    uint8_t *tlab = reinterpret_cast<uint8_t *>(tile + (size_t)F * TILE);    // [TILE]
-    long long *S = reinterpret_cast<long long *>(tlab + TILE);               // [KMAX][F]
-    int *cnt = reinterpret_cast<int *>(S + (size_t)KMAX * F);                // [KMAX]
-    int *changed = cnt + KMAX;                                               // [1]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long *S = reinterpret_cast<unsigned long long *>(smem);  // [COPIES][stride]
+    const int stride = km_copy_stride(KMAX, F);
+    const int lane = threadIdx.x & 63;
+    unsigned long long *myS = S + (size_t)(lane & (KM_COPIES - 1)) * stride;
     if (UPDATE) {
-        for (int i = threadIdx.x; i < KMAX * F; i += KM_THREADS) S[i] = 0;
-        if (threadIdx.x < KMAX) cnt[threadIdx.x] = 0;
-        if (threadIdx.x == 0) *changed = 0;
+        for (int i = threadIdx.x; i < KM_COPIES * stride; i += KM_THREADS) S[i] = 0ull;
+        __syncthreads();
     }
     T cs[KMAX];
 #pragma unroll
@@ -287,39 +304,36 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
         const int64_t tbase = chunk0 + (int64_t)t * TILE;
         if (tbase >= n) break;
         const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
-        if (UPDATE) __syncthreads();  // previous tile's phase B done (and initialisation visible)
+        T x[FR][PXL];
+#pragma unroll
+        for (int f = 0; f < FR; f++) {
+            if (f < F && base < n) load_px<T>(pl.p[f], base, n, x[f]);
+            else {
+#pragma unroll
+                for (int p = 0; p < PXL; p++) x[f][p] = (T)0;
+            }
+        }
         T acc[KMAX][PXL];
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
 #pragma unroll
             for (int p = 0; p < PXL; p++) acc[j][p] = (T)0;
-#pragma unroll 2
-        for (int f = 0; f < F; f++) {
-            T v[PXL];
-            if (base < n) load_px<T>(pl.p[f], base, n, v);
-            else {
 #pragma unroll
-                for (int p = 0; p < PXL; p++) v[p] = (T)0;
-            }
-            const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
-            T xc[PXL];
+        for (int f = 0; f < FR; f++) {
+            if (f < F) {
+                const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
 #pragma unroll
-            for (int p = 0; p < PXL; p++) xc[p] = scaled<T>(v[p], sc, mnv) - me;
-            if (UPDATE) {
-                typename vt<T>::vec o;
-                if constexpr (PXL == 4) o = make_float4(xc[0], xc[1], xc[2], xc[3]);
-                else o = make_double2(xc[0], xc[1]);
-                *reinterpret_cast<typename vt<T>::vec *>(tile + (size_t)f * TILE + threadIdx.x * PXL) = o;
-            }
+                for (int p = 0; p < PXL; p++) x[f][p] = scaled<T>(x[f][p], sc, mnv) - me;
 #pragma unroll
-            for (int j = 0; j < KMAX; j++) {
-                const T c = cenT[f * KMAX + j];
+                for (int j = 0; j < KMAX; j++) {
+                    const T c = cenT[f * KMAX + j];
 #pragma unroll
-                for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(xc[p], c, acc[j][p]);
+                    for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(x[f][p], c, acc[j][p]);
+                }
             }
         }
         // argmin with strict '<' (lowest index wins ties), _k_means_lloyd.pyx:206-213
-        uint8_t lab[PXL];
+        int lab[PXL];
 #pragma unroll
         for (int p = 0; p < PXL; p++) {
             T bd = tfma<T>((T)-2, acc[0][p], cs[0]);
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
                     if (d < bd) { bd = d; bl = j; }
                 }
             }
-            lab[p] = (uint8_t)bl;
+            lab[p] = bl;
         }
         if (base < n) {
             if (base + PXL <= n) {
@@ -348,44 +362,39 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
                 for (int p = 0; p < PXL; p++)
                     if (base + p < n) {
                         my_changed += labels[base + p] != lab[p];
-                        labels[base + p] = lab[p];
+                        labels[base + p] = (uint8_t)lab[p];
                     }
             }
         }
         if (UPDATE) {
+            // phase B.  Out-of-range pixels were loaded as 0 and must not be counted.
+            bool valid[PXL];
 #pragma unroll
-            for (int p = 0; p < PXL; p++) tlab[threadIdx.x * PXL + p] = (base + p < n) ? lab[p] : (uint8_t)255;
-            __syncthreads();
-            // phase B: wave w accumulates features w, w+4, ...; lanes sweep the tile
-            for (int f = wave; f < F; f += 4) {
-                for (int s = 0; s < TILE / (64 * PXL); s++) {
-                    const int px0 = (s * 64 + lane) * PXL;
-                    T xv[PXL];
-                    typename vt<T>::vec v = *reinterpret_cast<const typename vt<T>::vec *>(tile + (size_t)f * TILE + px0);
-                    unpack<T>(v, xv);
-                    uint8_t lb[PXL];
+            for (int p = 0; p < PXL; p++) valid[p] = base + p < n;
+            const bool same = PXL == 4 ? (lab[0] == lab[1] && lab[1] == lab[2] && lab[2] == lab[3] && valid[3])
+                                       : (lab[0] == lab[1] && valid[1]);
+            if (same) {
+                atomicAdd(&myS[KMAX * F + lab[0]], (unsigned long long)PXL);
+            } else {
 #pragma unroll
-                    for (int p = 0; p < PXL; p++) lb[p] = tlab[px0 + p];
+                for (int p = 0; p < PXL; p++)
+                    if (valid[p]) atomicAdd(&myS[KMAX * F + lab[p]], 1ull);
+            }
+#pragma unroll
+            for (int f = 0; f < FR; f++) {
+                if (f < F) {
                     long long q[PXL];
 #pragma unroll
-                    for (int p = 0; p < PXL; p++) q[p] = to_fixed40((double)xv[p]);
-                    for (int j = 0; j < k; j++) {
-                        long long v2 = 0;
-                        int c2 = 0;
+                    for (int p = 0; p < PXL; p++) q[p] = to_fixed40((double)x[f][p]);
+                    if (same) {  // one add for the lane's PXL pixels
+                        long long qs = q[0];
 #pragma unroll
-                        for (int p = 0; p < PXL; p++) {
-                            const bool m = lb[p] == j;
-                            v2 += m ? q[p] : 0;
-                            c2 += m;
-                        }
-                        if (__any(c2 != 0)) {
-                            long long tot = wave_sum(v2);
-                            if (f == 0) {
-                                int ct = wave_sum(c2);
-                                if (lane == 0) cnt[j] += ct;
-                            }
-                            if (lane == 0) S[(size_t)j * F + f] += tot;
-                        }
+                        for (int p = 1; p < PXL; p++) qs += q[p];
+                        atomicAdd(&myS[lab[0] * F + f], (unsigned long long)qs);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < PXL; p++)
+                            if (valid[p]) atomicAdd(&myS[lab[p] * F + f], (unsigned long long)q[p]);
                     }
                 }
             }
@@ -393,14 +402,19 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
     }
     if (UPDATE) {
         int ch = wave_sum(my_changed);
-        if (lane == 0 && ch) atomicAdd(changed, ch);
+        __shared__ int changed_w[4];
+        if (lane == 0) changed_w[threadIdx.x >> 6] = ch;
         __syncthreads();
         const int M = KMAX * F + KMAX + 1;
         for (int i = threadIdx.x; i < M; i += KM_THREADS) {
             long long v;
-            if (i < KMAX * F) v = S[i];
-            else if (i < KMAX * F + KMAX) v = cnt[i - KMAX * F];
-            else v = *changed;
+            if (i < KMAX * F + KMAX) {
+                unsigned long long a = 0;
+                for (int c = 0; c < KM_COPIES; c++) a += S[(size_t)c * stride + i];
+                v = (long long)a;
+            } else {
+                v = changed_w[0] + changed_w[1] + changed_w[2] + changed_w[3];
+            }
             partial[(size_t)i * nchunks + blockIdx.x] = v;
         }
     }
@@ -570,22 +584,32 @@ double now_ms()
 // combine {hi, lo} limb sums (km_reduce_cols) into one signed 128-bit value
 i128 limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
 
-template <typename T, int KMAX>
-void launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
+template <typename T, int KMAX, int FR>
+int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
                   const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial)
 {
-    if (update)
-        hipLaunchKernelGGL((km_lloyd<T, KMAX, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
+    if (update) {
+        static size_t attr = 48 * 1024;  // default dynamic-LDS limit without the attribute
+        if (lds > attr) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, FR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = lds;
+        }
+        hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
                            cenT, csq, labels, partial, nchunks);
-    else
-        hipLaunchKernelGGL((km_lloyd<T, KMAX, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
+    } else {
+        hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
                            cenT, csq, labels, partial, nchunks);
+    }
+    return RSSEG_OK;
 }
 
-template <typename T, int KMAX> int set_lloyd_attr(rsseg_ctx *ctx, size_t lds)
+template <typename T, int KMAX>
+int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
+                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial)
 {
-    HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return RSSEG_OK;
+    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
+    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
+    return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
 }
 
 template <typename T>
@@ -919,14 +943,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const double t_init = now_ms();
 
     // ---- Lloyd (_kmeans_single_lloyd) ----
-    const size_t lds = sizeof(T) * (size_t)F * TILE + TILE + sizeof(long long) * (size_t)KMAX * F + sizeof(int) * (KMAX + 1) + 64;
-    if (lds > 160 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d needs %zu B of LDS", F, lds);
-    switch (KMAX) {
-    case 8: RSCHK((set_lloyd_attr<T, 8>(ctx, lds))); break;
-    case 16: RSCHK((set_lloyd_attr<T, 16>(ctx, lds))); break;
-    case 32: RSCHK((set_lloyd_attr<T, 32>(ctx, lds))); break;
-    default: RSCHK((set_lloyd_attr<T, 64>(ctx, lds))); break;
-    }
+    const size_t lds = sizeof(long long) * (size_t)KM_COPIES * km_copy_stride(KMAX, F);
+    if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
     auto run_lloyd = [&](bool update) -> int {
         // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
         T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS], csq[RSSEG_MAX_CLUSTERS];
@@ -947,12 +965,14 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             {
                 prof_scope ps(ctx, "lloyd");
                 const size_t l2 = update ? lds : 0;
+                int lrc;
                 switch (KMAX) {
-                case 8: launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                case 16: launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                case 32: launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                default: launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
                 }
+                if (lrc != RSSEG_OK) return lrc;
             }
             HIPCHK(ctx, hipGetLastError());
             if (update) {
