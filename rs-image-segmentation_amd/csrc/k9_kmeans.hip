@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <type_traits>
 
 #include "common.h"
 
@@ -73,6 +74,23 @@ __device__ __forceinline__ void load_px(const void *plane, int64_t base, int64_t
     } else {
 #pragma unroll
         for (int i = 0; i < PXL; i++) o[i] = (base + i < n) ? p[base + i] : (T)0;
+    }
+}
+
+// FULL: the whole tile lies inside the plane, so the 16-byte load needs no bounds handling
+template <typename T, bool FULL>
+__device__ __forceinline__ void load_pxf(const void *plane, int64_t base, int64_t n, T *o)
+{
+    if constexpr (FULL) {
+        const T *p = reinterpret_cast<const T *>(plane);
+        typename vt<T>::vec v = *reinterpret_cast<const typename vt<T>::vec *>(p + base);
+        unpack<T>(v, o);
+    } else {
+        if (base < n) load_px<T>(plane, base, n, o);
+        else {
+#pragma unroll
+            for (int i = 0; i < vt<T>::PXL; i++) o[i] = (T)0;
+        }
     }
 }
 
@@ -165,29 +183,48 @@ __global__ void km_gather_row(planes_t pl, int F, int64_t idx, const scaler_t<T>
 }
 
 // ------------------------------------------------------------------------------------------------
-// k-means++ passes.  cand: [L][F] rows in T, cc: [L] float64 squared norms.
-//   MODE 0 (init):   closest = d2(cand0, x)                  ; partial[chunk] = sum fixed(closest)
-//   MODE 1 (eval):   for l < L: m_l = min(closest, d2(cand_l, x)); partial[l][chunk] = sum fixed(m_l)
-//   MODE 2 (update): closest = min(closest, d2(cand0, x))    ; partial[chunk] = sum fixed(closest)
-// one workgroup per chunk (km_chunk<T>() pixels), so partial[] is also the prefix table used to
-// locate the sampled pixel (np.searchsorted on stable_cumsum, _kmeans.py:243-246).
+// k-means++ pass (_kmeans.py:225-262).  candT: [F][KPP_MAXL] candidate rows upcast to float64 (transposed: one
+// scalar load per feature brings all candidates), cc: [L] float64 squared norms.
+//   closest_in == nullptr (first centre):  out[0] = d2(cand0, x)
+//   otherwise (one sampling round):        out[l] = min(closest_in, d2(cand_l, x))   for l < L
+// and partial[l][chunk] = sum over the chunk of fixed(out[l]).  One workgroup per chunk
+// (km_chunk<T>() pixels), so partial[l][] is at once the potential of candidate l and the prefix table
+// used to locate the next sampled pixel (np.searchsorted on stable_cumsum, _kmeans.py:243-246).
+// After the host has picked the best candidate its out[] plane simply BECOMES the closest-distance plane
+// (pointer swap): one pass per round, 4F + 4 + 4L B/px, instead of an evaluation pass plus an update pass.
+// As in km_lloyd the F feature vectors of a lane's pixels are requested back to back into registers.
 // ------------------------------------------------------------------------------------------------
 #define KPP_MAXL 8
-template <typename T, int MODE>
+template <typename T, int NL> struct kpp_out_t {
+    T *p[NL];
+};
+
+template <typename T, int NL, int FR>
 __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t n, const scaler_t<T> *__restrict__ sp,
-                                                     const T *__restrict__ cand, const double *__restrict__ cc, int L,
-                                                     T *__restrict__ closest, unsigned long long *__restrict__ partial,
-                                                     int64_t nchunks)
+                                                     const double *__restrict__ candT, const double *__restrict__ cc, int L,
+                                                     const T *__restrict__ closest_in, kpp_out_t<T, NL> out,
+                                                     unsigned long long *__restrict__ partial, int64_t nchunks)
 {
     constexpr int PXL = vt<T>::PXL;
-    constexpr int NL = MODE == 1 ? KPP_MAXL : 1;
     unsigned long long acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) acc[l] = 0;
     const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
-    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
-        const int64_t base = chunk0 + (int64_t)t * km_tile<T>() + (int64_t)threadIdx.x * PXL;
-        if (base >= n) break;
+    auto tile_body = [&](auto full_t, int64_t base) {
+        constexpr bool FULL = decltype(full_t)::value;
+        T x[FR][PXL];
+#pragma unroll
+        for (int f = 0; f < FR; f++) {
+            if (f < F) load_pxf<T, FULL>(pl.p[f], base, n, x[f]);
+            else {
+#pragma unroll
+                for (int p = 0; p < PXL; p++) x[f][p] = (T)0;
+            }
+        }
+        T cl[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) cl[p] = (T)0;
+        if (closest_in != nullptr) load_pxf<T, FULL>(closest_in, base, n, cl);
         double dot[NL][PXL], yy[PXL];
 #pragma unroll
         for (int p = 0; p < PXL; p++) {
@@ -195,49 +232,56 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
 #pragma unroll
             for (int l = 0; l < NL; l++) dot[l][p] = 0.0;
         }
-        for (int f = 0; f < F; f++) {
-            T v[PXL];
-            load_px<T>(pl.p[f], base, n, v);
-            const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
 #pragma unroll
-            for (int p = 0; p < PXL; p++) {
-                const double y = (double)(scaled<T>(v[p], sc, mnv) - me);
-                yy[p] = fma(y, y, yy[p]);
+        for (int f = 0; f < FR; f++) {
+            if (f < F) {
+                const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+                double cd[NL];  // unconditional: candT is padded to KPP_MAXL columns (zeros beyond L)
 #pragma unroll
-                for (int l = 0; l < NL; l++)
-                    if (l < L) dot[l][p] = fma((double)cand[l * F + f], y, dot[l][p]);
-            }
-        }
-        T cl[PXL];
-        if (MODE != 0) load_px<T>(closest, base, n, cl);
-        T outv[PXL];
+                for (int l = 0; l < NL; l++) cd[l] = candT[f * KPP_MAXL + l];
 #pragma unroll
-        for (int p = 0; p < PXL; p++) {
+                for (int p = 0; p < PXL; p++) {
+                    const double y = (double)(scaled<T>(x[f][p], sc, mnv) - me);
+                    yy[p] = fma(y, y, yy[p]);
 #pragma unroll
-            for (int l = 0; l < NL; l++) {
-                if (l < L) {
-                    double d = -2.0 * dot[l][p];
-                    d = d + cc[l];
-                    d = d + yy[p];
-                    T dt = (T)d;
-                    dt = dt > (T)0 ? dt : (T)0;  // np.maximum(distances, 0)
-                    if (MODE != 0) dt = cl[p] < dt ? cl[p] : dt;  // np.minimum(closest, d)
-                    if (base + p < n) acc[l] += (unsigned long long)to_fixed40((double)dt);
-                    if (l == 0) outv[p] = dt;
+                    for (int l = 0; l < NL; l++) dot[l][p] = fma(cd[l], y, dot[l][p]);
                 }
             }
         }
-        if (MODE != 1) {
-            if (base + PXL <= n) {
-                typename vt<T>::vec o;
-                if constexpr (PXL == 4) o = make_float4(outv[0], outv[1], outv[2], outv[3]);
-                else o = make_double2(outv[0], outv[1]);
-                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
-            } else {
-                for (int p = 0; p < PXL; p++)
-                    if (base + p < n) closest[base + p] = outv[p];
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            if (l < L) {
+                const double ccl = cc[l];
+                T outv[PXL];
+#pragma unroll
+                for (int p = 0; p < PXL; p++) {
+                    double d = -2.0 * dot[l][p];
+                    d = d + ccl;
+                    d = d + yy[p];
+                    T dt = (T)d;
+                    dt = dt > (T)0 ? dt : (T)0;                                   // np.maximum(distances, 0)
+                    if (closest_in != nullptr) dt = cl[p] < dt ? cl[p] : dt;     // np.minimum(closest, d)
+                    if (FULL || base + p < n) acc[l] += (unsigned long long)to_fixed40((double)dt);
+                    outv[p] = dt;
+                }
+                if (FULL || base + PXL <= n) {
+                    typename vt<T>::vec o;
+                    if constexpr (PXL == 4) o = make_float4(outv[0], outv[1], outv[2], outv[3]);
+                    else o = make_double2(outv[0], outv[1]);
+                    *reinterpret_cast<typename vt<T>::vec *>(out.p[l] + base) = o;
+                } else {
+                    for (int p = 0; p < PXL; p++)
+                        if (base + p < n) out.p[l][base + p] = outv[p];
+                }
             }
         }
+    };
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t tbase = chunk0 + (int64_t)t * km_tile<T>();
+        if (tbase >= n) break;
+        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+        if (tbase + km_tile<T>() <= n) tile_body(std::true_type{}, base);
+        else tile_body(std::false_type{}, base);
     }
     __shared__ unsigned long long sacc[4][NL];
 #pragma unroll
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
         if (lane_id() == 0) sacc[threadIdx.x >> 6][l] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NL && (int)threadIdx.x < (MODE == 1 ? L : 1))
+    if ((int)threadIdx.x < NL && (int)threadIdx.x < L)
         partial[(size_t)threadIdx.x * nchunks + blockIdx.x] =
             sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x];
 }
@@ -300,14 +344,12 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
     for (int j = 0; j < KMAX; j++) cs[j] = csq[j];
     const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
     int my_changed = 0;
-    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
-        const int64_t tbase = chunk0 + (int64_t)t * TILE;
-        if (tbase >= n) break;
-        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+    auto tile_body = [&](auto full_t, int64_t base) {
+        constexpr bool FULL = decltype(full_t)::value;
         T x[FR][PXL];
 #pragma unroll
         for (int f = 0; f < FR; f++) {
-            if (f < F && base < n) load_px<T>(pl.p[f], base, n, x[f]);
+            if (f < F) load_pxf<T, FULL>(pl.p[f], base, n, x[f]);
             else {
 #pragma unroll
                 for (int p = 0; p < PXL; p++) x[f][p] = (T)0;
@@ -322,14 +364,15 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
         for (int f = 0; f < FR; f++) {
             if (f < F) {
                 const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+                T cj[KMAX];
+#pragma unroll
+                for (int j = 0; j < KMAX; j++) cj[j] = cenT[f * KMAX + j];
 #pragma unroll
                 for (int p = 0; p < PXL; p++) x[f][p] = scaled<T>(x[f][p], sc, mnv) - me;
 #pragma unroll
-                for (int j = 0; j < KMAX; j++) {
-                    const T c = cenT[f * KMAX + j];
+                for (int j = 0; j < KMAX; j++)
 #pragma unroll
-                    for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(x[f][p], c, acc[j][p]);
-                }
+                    for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(x[f][p], cj[j], acc[j][p]);
             }
         }
         // argmin with strict '<' (lowest index wins ties), _k_means_lloyd.pyx:206-213
@@ -347,32 +390,31 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
             }
             lab[p] = bl;
         }
-        if (base < n) {
-            if (base + PXL <= n) {
-                if constexpr (PXL == 4) {
-                    uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
-                    my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
-                    *reinterpret_cast<uchar4 *>(labels + base) = make_uchar4(lab[0], lab[1], lab[2], lab[3]);
-                } else {
-                    uchar2 old = *reinterpret_cast<const uchar2 *>(labels + base);
-                    my_changed += (old.x != lab[0]) + (old.y != lab[1]);
-                    *reinterpret_cast<uchar2 *>(labels + base) = make_uchar2(lab[0], lab[1]);
-                }
+        if (FULL || base + PXL <= n) {
+            if constexpr (PXL == 4) {
+                uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
+                my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
+                *reinterpret_cast<uchar4 *>(labels + base) = make_uchar4(lab[0], lab[1], lab[2], lab[3]);
             } else {
-                for (int p = 0; p < PXL; p++)
-                    if (base + p < n) {
-                        my_changed += labels[base + p] != lab[p];
-                        labels[base + p] = (uint8_t)lab[p];
-                    }
+                uchar2 old = *reinterpret_cast<const uchar2 *>(labels + base);
+                my_changed += (old.x != lab[0]) + (old.y != lab[1]);
+                *reinterpret_cast<uchar2 *>(labels + base) = make_uchar2(lab[0], lab[1]);
             }
+        } else {
+            for (int p = 0; p < PXL; p++)
+                if (base + p < n) {
+                    my_changed += labels[base + p] != lab[p];
+                    labels[base + p] = (uint8_t)lab[p];
+                }
         }
         if (UPDATE) {
             // phase B.  Out-of-range pixels were loaded as 0 and must not be counted.
             bool valid[PXL];
 #pragma unroll
-            for (int p = 0; p < PXL; p++) valid[p] = base + p < n;
-            const bool same = PXL == 4 ? (lab[0] == lab[1] && lab[1] == lab[2] && lab[2] == lab[3] && valid[3])
-                                       : (lab[0] == lab[1] && valid[1]);
+            for (int p = 0; p < PXL; p++) valid[p] = FULL || base + p < n;
+            bool same = valid[PXL - 1];
+#pragma unroll
+            for (int p = 1; p < PXL; p++) same = same && lab[p] == lab[0];
             if (same) {
                 atomicAdd(&myS[KMAX * F + lab[0]], (unsigned long long)PXL);
             } else {
@@ -399,6 +441,13 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
                 }
             }
         }
+    };
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t tbase = chunk0 + (int64_t)t * TILE;
+        if (tbase >= n) break;
+        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+        if (tbase + TILE <= n) tile_body(std::true_type{}, base);
+        else tile_body(std::false_type{}, base);
     }
     if (UPDATE) {
         int ch = wave_sum(my_changed);
@@ -612,6 +661,32 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
     return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
 }
 
+template <typename T, int NL, int FR>
+void launch_kpp3(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
+                 int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+{
+    kpp_out_t<T, NL> o;
+    for (int l = 0; l < NL; l++) o.p[l] = l < L ? outs[l] : nullptr;
+    hipLaunchKernelGGL((km_kpp<T, NL, FR>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest_in, o,
+                       partial, nchunks);
+}
+template <typename T, int NL>
+void launch_kpp2(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
+                 int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+{
+    if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+}
+template <typename T>
+void launch_kpp(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
+                int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+{
+    if (L <= 1) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+}
+
 template <typename T>
 int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, int k, uint32_t seed, int max_iter, double tol_in,
                int32_t *d_labels, double *centers_out, rsseg_kmeans_info *info)
@@ -644,14 +719,15 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_sp = carve(sizeof(scaler_t<T>));
     const size_t o_cen = carve(sizeof(T) * KMAX * RSSEG_MAX_FEATURES);
     const size_t o_csq = carve(sizeof(T) * KMAX);
-    const size_t o_cand = carve(sizeof(T) * KPP_MAXL * RSSEG_MAX_FEATURES);
+    const size_t o_cand = carve(sizeof(double) * KPP_MAXL * RSSEG_MAX_FEATURES);
     const size_t o_cc = carve(sizeof(double) * KPP_MAXL);
     const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
     const size_t o_red = carve(sizeof(long long) * 2 * M);
     const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
     const size_t o_mom = carve(sizeof(long long) * (size_t)nblk * F);
     const size_t o_part = carve(sizeof(long long) * std::max<size_t>((size_t)M, KPP_MAXL) * (size_t)nchunks);
-    const size_t o_closest = carve(sizeof(T) * (size_t)std::max<int64_t>(n, 1) + 64);
+    const size_t dist_stride = (sizeof(T) * (size_t)std::max<int64_t>(n, 1) + 255) & ~(size_t)255;
+    const size_t o_closest = carve(dist_stride * (size_t)(L + 1));
     const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
@@ -662,14 +738,16 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     scaler_t<T> *d_sp = (scaler_t<T> *)(ws + o_sp);
     T *d_cen = (T *)(ws + o_cen);
     T *d_csq = (T *)(ws + o_csq);
-    T *d_cand = (T *)(ws + o_cand);
+    double *d_cand = (double *)(ws + o_cand);
     double *d_cc = (double *)(ws + o_cc);
     T *d_row = (T *)(ws + o_row);
     long long *d_red = (long long *)(ws + o_red);
     T *d_mm = (T *)(ws + o_mm);
     long long *d_mom = (long long *)(ws + o_mom);
     long long *d_part = (long long *)(ws + o_part);
-    T *d_closest = (T *)(ws + o_closest);
+    T *d_dist[KPP_MAXL + 1];  // L + 1 distance planes: the current closest-distance plane and L candidate planes
+    for (int l = 0; l <= L; l++) d_dist[l] = (T *)(ws + o_closest + dist_stride * (size_t)l);
+    T *d_closest = d_dist[0];
     uint8_t *d_lab = (uint8_t *)(ws + o_lab);
     hipStream_t st = ctx->stream;
 
@@ -795,17 +873,18 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         return RSSEG_OK;
     };
     auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt) -> int {
-        T flat[KPP_MAXL * RSSEG_MAX_FEATURES];
+        double flat[KPP_MAXL * RSSEG_MAX_FEATURES];
         double cc[KPP_MAXL];
+        memset(flat, 0, sizeof(flat));
         for (int l = 0; l < cnt; l++) {
             double a = 0.0;
             for (int f = 0; f < F; f++) {
-                flat[l * F + f] = rows[l][f];
+                flat[f * KPP_MAXL + l] = (double)rows[l][f];
                 a = std::fma((double)rows[l][f], (double)rows[l][f], a);
             }
             cc[l] = a;
         }
-        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(T) * cnt * F, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(double) * KPP_MAXL * F, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(d_cc, cc, sizeof(double) * cnt, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));  // flat/cc live on this stack frame
         return RSSEG_OK;
@@ -849,8 +928,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         RSCHK(upload_cands(rows, 1));
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
-            hipLaunchKernelGGL((km_kpp<T, 0>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, 1, d_closest,
-                               (unsigned long long *)d_part, nchunks);
+            T *outs0[1] = {d_closest};
+            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, (const T *)nullptr, outs0, (unsigned long long *)d_part);
         }
         HIPCHK(ctx, hipGetLastError());
     }
@@ -861,6 +940,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     std::vector<unsigned long long> prefix_part((size_t)nchunks);  // this rank's closest-dist chunk sums
     for (int64_t c = 0; c < nchunks; c++) prefix_part[c] = h_part[c];
 
+    T *cand_planes[KPP_MAXL] = {nullptr};
     for (int c = 1; c < k; c++) {
         int64_t cand_idx[KPP_MAXL];
         double found[KPP_MAXL];
@@ -906,8 +986,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         RSCHK(upload_cands(rows, L));
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
-            hipLaunchKernelGGL((km_kpp<T, 1>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, L, d_closest,
-                               (unsigned long long *)d_part, nchunks);
+            T *outs[KPP_MAXL];
+            for (int l = 0, sl = 0; l < L; l++, sl++) {
+                if (d_dist[sl] == d_closest) sl++;
+                outs[l] = d_dist[sl];
+            }
+            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, L, (const T *)d_closest, outs, (unsigned long long *)d_part);
+            for (int l = 0; l < L; l++) cand_planes[l] = outs[l];
         }
         HIPCHK(ctx, hipGetLastError());
         RSCHK(pull_partials(L));
@@ -922,21 +1007,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         current_pot = best_pot;
         for (int f = 0; f < F; f++) C[c][f] = rows[best][f];
         init_idx[c] = cand_idx[best];
-        // closest = min(closest, d2(best)) and the new prefix table
-        T one[KPP_MAXL][RSSEG_MAX_FEATURES];
-        for (int f = 0; f < F; f++) one[0][f] = rows[best][f];
-        RSCHK(upload_cands(one, 1));
-        if (n > 0) {
-            prof_scope ps(ctx, "kpp");
-            hipLaunchKernelGGL((km_kpp<T, 2>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, st, pl, F, n, d_sp, d_cand, d_cc, 1, d_closest,
-                               (unsigned long long *)d_part, nchunks);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        if (c + 1 < k) {
-            RSCHK(pull_partials(1));
-            RSCHK(global_total(0, rank_tot, &total));
-            for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[cc2];
-        }
+        // the best candidate's plane becomes the closest-distance plane; its chunk sums the prefix table
+        if (n > 0) d_closest = cand_planes[best];
+        RSCHK(global_total(best, rank_tot, &total));
+        for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[(size_t)best * nchunks + cc2];
     }
     if (info)
         for (int j = 0; j < k; j++) info->init_indices[j] = init_idx[j];

@@ -103,7 +103,6 @@ def robust_scaler_stats(ctx, plane, n_global: int = None) -> Tuple[np.float32, n
     """RobustScaler.fit for one column (sklearn/preprocessing/_data.py:1656-1677): center_ =
     np.nanmedian (float32), scale_ = nanpercentile 75 - nanpercentile 25 (float64), zero -> 1."""
     n = int(plane.numel()) if n_global is None else int(n_global)
-    _, n_nan = ctx.order_stats(plane, [0]) if False else (None, 0)
     mr, mfin = median_plan(n, np.float32)
     pr, pfin = percentile_plan(n, (25.0, 75.0), np.float32, False)
     vals, n_nan = ctx.order_stats(plane, mr + pr)

@@ -24,6 +24,30 @@ def _torch():
     return torch
 
 
+def make_allreduce_hook(buf, group=None):
+    """The Python side of rsseg_allreduce_fn: reduces `count` elements of `dtype` at byte `offset` of the
+    communication buffer `buf` (a uint8 tensor; on the GPU in production, so the collective is RCCL over
+    xGMI; a CPU tensor with the gloo backend in the CPU tests) in place across the ranks of `group`."""
+    torch = _torch()
+    import torch.distributed as dist
+    views = {L.F32: torch.float32, L.F64: torch.float64, L.I64: torch.int64}
+    ops = {L.SUM: dist.ReduceOp.SUM, L.MIN: dist.ReduceOp.MIN, L.MAX: dist.ReduceOp.MAX}
+
+    def hook(_user, offset, count, dtype, op):
+        try:
+            esz = 4 if dtype == L.F32 else 8
+            t = buf[offset:offset + count * esz].view(views[dtype])
+            dist.all_reduce(t, op=ops[op], group=group)
+            if buf.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as e:  # noqa: BLE001 — must not propagate through the C frame
+            print(f"[rsseg] all-reduce hook failed: {e!r}", flush=True)
+            return 1
+
+    return hook
+
+
 class Context:
     """Owns an rsseg_ctx.  `group` (optional) is a torch.distributed process group: when its world
     size is > 1 the library's reductions go through RCCL (or gloo in CPU tests of the hook)."""
@@ -56,25 +80,9 @@ class Context:
         import torch.distributed as dist
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self._comm_buf = torch.zeros(1 << 21, dtype=torch.uint8, device=self.device)
-        views = {L.F32: torch.float32, L.F64: torch.float64, L.I64: torch.int64}
-        ops = {L.SUM: dist.ReduceOp.SUM, L.MIN: dist.ReduceOp.MIN, L.MAX: dist.ReduceOp.MAX}
-        buf = self._comm_buf
-
-        def hook(_user, offset, count, dtype, op):
-            try:
-                dt = views[dtype]
-                esz = 4 if dtype == L.F32 else 8
-                t = buf[offset:offset + count * esz].view(dt)
-                dist.all_reduce(t, op=ops[op], group=group)
-                torch.cuda.current_stream().synchronize()
-                return 0
-            except Exception as e:  # noqa: BLE001 — must not propagate through the C frame
-                print(f"[rsseg] all-reduce hook failed: {e!r}", flush=True)
-                return 1
-
-        self._hook = L.ALLREDUCE_FN(hook)
+        self._hook = L.ALLREDUCE_FN(make_allreduce_hook(self._comm_buf, group))
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
-                                              C.c_void_p(buf.data_ptr()), buf.numel()))
+                                              C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
 
     def close(self):
         if getattr(self, "h", None):

@@ -1,0 +1,76 @@
+"""
+Counterparts of the two stage functions that bracket the hot path:
+
+  run_feature_extraction_stage   reference scripts/2_feature_extraction.py:27-133
+  run_classification_stage       reference scripts/3_classification.py:267-505 (KMeans and forest branches)
+
+They keep the reference's return values and on-disk layout (.npy of the (H, W, C) float64 stacks,
+scripts/2:193-214; pickle with 'hierarchical_features' / 'all_extracted_features_dict' / 'dimensions',
+scripts/2:222-232; label maps as .npy), but run the whole chain on the device with ONE upload of the
+bands and one download per product, instead of a host round trip per function as the per-function
+mirrors in modules/ do.  Plotting (scripts/2:131, 267-385; scripts/3:491) is out of scope.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import pipeline as P
+from .runtime import Context, default_context
+
+
+def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing: bool = True, texture_band_index: int = 3,
+                                 ctx: Optional[Context] = None) -> Tuple[Dict, Dict]:
+    """bands_data: list of >= 5 (H, W) arrays in TM band order.  `texture_band_index` is accepted and
+    ignored exactly as in the reference (NIR = bands[3] is hard-wired, scripts/2:84)."""
+    if not preprocessing:
+        raise ValueError("run_feature_extraction_stage: preprocessing=False is not implemented (the reference never uses it)")
+    ctx = ctx or default_context()
+    h, w = np.asarray(bands_data[0]).shape
+    dev = [ctx.to_device(np.ascontiguousarray(b, dtype=np.float32).reshape(-1)) for b in bands_data if b is not None]
+    planes, ex = P.feature_stack19(ctx, dev, h, w)
+
+    def host(t):
+        return t.cpu().numpy().reshape(h, w)
+
+    fd: Dict[str, object] = {k: host(v) for k, v in ex["indices"].items()}
+    fd["pca_result"] = [host(p) for p in ex["pca"]]
+    fd["variance_ratio"] = ex["pca_ratio"]
+    fd["glcm_features"] = {k: host(v) for k, v in ex["glcm"].items()}
+    fd["morphological_features"] = {"gradient_5": host(planes[16]) / 255.0}
+    fd["multi_scale_features"] = {"std_dev_scale_5": host(planes[17])}
+    fd["filter_features"] = {"sobel_mag": host(planes[18])}
+    stack = P.stack19_to_host(planes, h, w)
+    hier = {"level_1": np.ascontiguousarray(stack[:, :, :14]), "level_2": np.ascontiguousarray(stack[:, :, 14:]), "all": stack}
+    return fd, hier
+
+
+def save_feature_outputs(output_dir: str, features_dict: Dict, hierarchical_features: Dict, height: int, width: int,
+                         transform=None, crs=None) -> Dict[str, str]:
+    """File names and contents of scripts/2:193-232."""
+    os.makedirs(output_dir, exist_ok=True)
+    paths = {"level1": os.path.join(output_dir, "level1_features.npy"),
+             "level2": os.path.join(output_dir, "level2_features.npy"),
+             "all": os.path.join(output_dir, "all_hierarchical_features.npy"),
+             "pkl": os.path.join(output_dir, "all_features_and_metadata.pkl")}
+    np.save(paths["level1"], hierarchical_features["level_1"])
+    np.save(paths["level2"], hierarchical_features["level_2"])
+    np.save(paths["all"], hierarchical_features["all"])
+    with open(paths["pkl"], "wb") as f:
+        pickle.dump({"hierarchical_features": hierarchical_features, "all_extracted_features_dict": features_dict,
+                     "dimensions": (height, width), "geo_transform": transform, "crs": crs}, f)
+    return paths
+
+
+def run_kmeans_stage(hierarchical_all: np.ndarray, n_clusters: int = 7, ctx: Optional[Context] = None) -> np.ndarray:
+    """KMeans branch of run_classification_stage on the 19-feature stack: labels + 1 as uint8
+    (scripts/3:390-394, 509-538: final_map = labels + 1, saved as uint8 with nodata 0)."""
+    ctx = ctx or default_context()
+    h, w, c = hierarchical_all.shape
+    dt = np.float32 if hierarchical_all.dtype == np.float32 else np.float64
+    dev = [ctx.to_device(np.ascontiguousarray(hierarchical_all[:, :, i], dtype=dt).reshape(-1)) for i in range(c)]
+    labels, _ = ctx.kmeans_fit_predict(dev, n_clusters)
+    return (labels.cpu().numpy().reshape(h, w) + 1).astype(np.uint8)
