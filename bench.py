@@ -58,6 +58,25 @@ def algorithmic_bytes_per_px(family, F, glcm_step):
     }[family]
 
 
+# kernel family -> name of its dominant kernel in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
+PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16>", "glcm": "k4_glcm_thread<7>",
+              "select": "k1_hist<0>", "indices": "k2_indices", "gram": "k3_gram", "project": "k3_project", "resize": "k5_resize"}
+
+
+def pmc_traffic_bytes(family, px):
+    """HBM bytes per launch of the family's dominant kernel from the committed PMC summary (FETCH_SIZE
+    doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None when no summary is available."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files or family not in PMC_KERNEL:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(PMC_KERNEL[family])
+        return None if k is None else round((k["read_B_per_px"] + k["write_B_per_px"]) * px)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(O, tile_bands, H, W, crop, cfg, k):
     """Oracle ("port", single thread) on a crop of the same raster; returns (Mpx/s, description)."""
     from threadpoolctl import threadpool_limits
@@ -86,7 +105,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c2", "c3"])
     ap.add_argument("--size", type=int, default=0, help="tile edge (default 16384 for c3, 4096 for c2)")
     ap.add_argument("--glcm-step", type=int, default=1)
-    ap.add_argument("--cpu-crop", type=int, default=768)
+    ap.add_argument("--cpu-crop", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -157,7 +176,8 @@ def main():
             bpp = algorithmic_bytes_per_px(dom, F, args.glcm_step)
             achieved = px * bpp / per_launch_s / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_bytes(dom, px) if H == 16384 else None,
+                    "algorithmic_bytes": round(px * bpp),
                     "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": cnt / args.steps,
                     "family_ms_per_step": {f: round(v[0] / args.steps, 3) for f, v in fams.items()}}
         cpu = None
