@@ -209,15 +209,8 @@ def run_c2(ctx, P, bands, k, n_global):
 
 
 def run_c3(ctx, P, bands, H, W, k, glcm_step, n_global):
-    lohi = P.band_lohi(ctx, bands, n_global)
-    idx, norms = P.spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
-    norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
-    pcs, _, _ = P.pca(ctx, norm_all, 3, True, n_global)
-    nir2 = P.renormalize(ctx, norm_all[3], n_global)
-    del norm_all, norms
-    glcm, _ = P.glcm_features(ctx, nir2, H, W, 32, 7, glcm_step)
-    planes = [idx[n] for n in P.INDEX_NAMES] + [glcm[n] for n in P.GLCM_NAMES] + list(pcs)
-    return ctx.kmeans_fit_predict(planes, k)
+    labels, meta, _ = P.config3(ctx, bands, H, W, k, 7, glcm_step, 3, n_global)
+    return labels, meta
 
 
 if __name__ == "__main__":

@@ -61,9 +61,9 @@ typedef unsigned __int128 u128;
  *
  * mode 0 ("literal"): builds the 4 normalised matrices and evaluates graycoprops' formulas on
  *         them in float64, row-major.  This is the restatement of skimage.
- * mode 1 ("pairs"):   the same five properties from exact integer pair statistics; this is the
- *         bit-exact specification the HIP kernel implements ("GLCM numerics").
- *         tests/test_oracle.py checks mode 0 == mode 1 to 1e-12.
+ * mode 1 ("pairs"):   the same five properties from exact integer pair statistics, the mean over the
+ *         angles taken over a common denominator; this is the bit-exact specification the HIP kernel
+ *         implements.  tests/test_oracle.py checks mode 0 == mode 1 to 1e-6.
  * ------------------------------------------------------------------------------------------ */
 static const int GLCM_DR[4] = {0, 1, 1, 1};
 static const int GLCM_DC[4] = {1, 1, 0, -1};
@@ -84,6 +84,7 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
         for (int oj = 0; oj < ow; oj++) {
             const uint8_t *wp = q + (size_t)(oi * step) * W + (size_t)oj * step;
             double pc[4], pd[4], ph[4], pe[4], pr[4];
+            int64_t aS1[4], aS2[4], aHq[4], aA[4], aNp[4];
             for (int a = 0; a < 4; a++) {
                 const int dr = GLCM_DR[a], dc = GLCM_DC[a];
                 const int r0 = dr < 0 ? -dr : 0, r1 = dr > 0 ? win - dr : win;
@@ -137,22 +138,42 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
                             int64_t g = (int64_t)G[i * levels + j] + (int64_t)G[j * levels + i];
                             A += g * g;
                         }
-                    const double npd = (double)np, tot = (double)(2 * np);
-                    if (np == 0) { pc[a] = pd[a] = ph[a] = pe[a] = 0.0; pr[a] = 1.0; continue; }
-                    pc[a] = (double)S2 / npd;
-                    pd[a] = (double)S1 / npd;
-                    ph[a] = ((double)Hq * (1.0 / 4503599627370496.0)) / npd;
-                    pe[a] = sqrt((double)A / (tot * tot));
+                    aS1[a] = S1; aS2[a] = S2; aHq[a] = Hq; aA[a] = A; aNp[a] = np;
                     int64_t den = M2 * (2 * np) - M1 * M1, num = Mx * (2 * np) - M1 * M1;
                     pr[a] = den == 0 ? 1.0 : (double)num / (double)den;
                 }
             }
             const size_t o = (size_t)oi * ow + oj;
-            contrast[o] = (float)((((pc[0] + pc[1]) + pc[2]) + pc[3]) / 4.0);
-            dissim[o] = (float)((((pd[0] + pd[1]) + pd[2]) + pd[3]) / 4.0);
-            homog[o] = (float)((((ph[0] + ph[1]) + ph[2]) + ph[3]) / 4.0);
-            energy[o] = (float)((((pe[0] + pe[1]) + pe[2]) + pe[3]) / 4.0);
-            corr[o] = (float)((((pr[0] + pr[1]) + pr[2]) + pr[3]) / 4.0);
+            if (mode == 0) {
+                contrast[o] = (float)((((pc[0] + pc[1]) + pc[2]) + pc[3]) / 4.0);
+                dissim[o] = (float)((((pd[0] + pd[1]) + pd[2]) + pd[3]) / 4.0);
+                homog[o] = (float)((((ph[0] + ph[1]) + ph[2]) + ph[3]) / 4.0);
+                energy[o] = (float)((((pe[0] + pe[1]) + pe[2]) + pe[3]) / 4.0);
+                corr[o] = (float)((((pr[0] + pr[1]) + pr[2]) + pr[3]) / 4.0);
+            } else {
+                /* mode 1 precondition: every pixel < levels, so np depends on the geometry only:
+                 * na = win*(win-1) for 0/90 degrees, nb = (win-1)^2 for 45/135 degrees.  The mean over
+                 * the angles is taken over the common denominator 4*na*nb (one division per property). */
+                const int64_t na = aNp[0], nb = aNp[1];
+                if (aNp[2] != na || aNp[3] != nb || na == 0 || nb == 0) { free(G); free(P); return -3; }
+                const double dna = (double)na, dnb = (double)nb;
+                const double den4 = (double)(4 * na * nb), den8 = (double)(8 * na * nb);
+                contrast[o] = (float)((double)((aS2[0] + aS2[2]) * nb + (aS2[1] + aS2[3]) * na) / den4);
+                dissim[o] = (float)((double)((aS1[0] + aS1[2]) * nb + (aS1[1] + aS1[3]) * na) / den4);
+                {
+                    const double t1 = (double)(aHq[1] + aHq[3]) * dna;
+                    const double num = fma((double)(aHq[0] + aHq[2]), dnb, t1);
+                    homog[o] = (float)((num / den4) * (1.0 / 4503599627370496.0));
+                }
+                {
+                    const double s02 = sqrt((double)aA[0]) + sqrt((double)aA[2]);
+                    const double s13 = sqrt((double)aA[1]) + sqrt((double)aA[3]);
+                    const double t1 = s13 * dna;
+                    const double num = fma(s02, dnb, t1);
+                    energy[o] = (float)(num / den8);
+                }
+                corr[o] = (float)((((pr[0] + pr[1]) + pr[2]) + pr[3]) * 0.25);
+            }
         }
     }
     free(G); free(P);

@@ -19,19 +19,54 @@ __device__ __forceinline__ uint32_t f32_key(float x, bool &is_nan)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// pass 0: shift 21, no prefix.  pass 1: prefix = key >> 21, bin = (key >> 10) & 2047.
-// pass 2: prefix = key >> 10, bin = key & 1023.
+// pass 0: bin = key >> 21 (one table).
+// pass 1: prefix = key >> 21 (11 bits), bin = (key >> 10) & 2047, one 2048-bin table per live prefix.
+// pass 2: prefix = key >> 10 (22 bits), bin = key & 1023.
+// Which table an element feeds is found with O(1) LDS byte lookups, not a scan of the live prefixes:
+// tab1[key >> 21] = slot of the 11-bit prefix (255 = not wanted); pass 2 adds tab2[slot1][(key >> 10) & 2047].
+#define SEL_NONE 255u
 template <int PASS>
 __global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__ x, int64_t n,
                                                        const uint32_t *__restrict__ prefixes, int nprefix,
                                                        unsigned long long *__restrict__ hist,
                                                        unsigned long long *__restrict__ nan_count)
 {
-    extern __shared__ uint32_t lh[];  // nprefix * SEL_BINS
-    const int nb = (PASS == 0 ? 1 : nprefix) * SEL_BINS;
+    extern __shared__ uint32_t lh[];  // [ntab][SEL_BINS] counters, then the byte lookup tables
+    const int ntab = PASS == 0 ? 1 : nprefix;
+    const int nb = ntab * SEL_BINS;
+    uint8_t *tab1 = reinterpret_cast<uint8_t *>(lh + nb);  // [2048]
+    uint8_t *tab2 = tab1 + SEL_BINS;                       // [n1][2048], pass 2 only
+    __shared__ uint32_t p1list[RSSEG_MAX_RANKS];
+    __shared__ int n1s;
     for (int i = threadIdx.x; i < nb; i += SEL_THREADS) lh[i] = 0;
-    __shared__ uint32_t spre[RSSEG_MAX_RANKS];
-    if (PASS != 0 && threadIdx.x < nprefix) spre[threadIdx.x] = prefixes[threadIdx.x];
+    if (PASS != 0) {
+        for (int i = threadIdx.x; i < SEL_BINS; i += SEL_THREADS) tab1[i] = SEL_NONE;
+        if (threadIdx.x == 0) {
+            int n1 = 0;  // distinct 11-bit prefixes
+            for (int j = 0; j < nprefix; j++) {
+                const uint32_t p1 = PASS == 1 ? prefixes[j] : (prefixes[j] >> 11);
+                bool seen = false;
+                for (int t = 0; t < n1; t++) seen = seen || p1list[t] == p1;
+                if (!seen) p1list[n1++] = p1;
+            }
+            n1s = n1;
+        }
+        __syncthreads();
+        if (PASS == 2)
+            for (int i = threadIdx.x; i < n1s * SEL_BINS; i += SEL_THREADS) tab2[i] = SEL_NONE;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 0; t < n1s; t++) tab1[p1list[t]] = (uint8_t)t;
+            if (PASS == 1) {
+                for (int j = 0; j < nprefix; j++) tab1[prefixes[j]] = (uint8_t)j;  // slot = table index
+            } else {
+                for (int j = 0; j < nprefix; j++) {
+                    const uint32_t p1 = prefixes[j] >> 11, mid = prefixes[j] & 2047u;
+                    tab2[(size_t)tab1[p1] * SEL_BINS + mid] = (uint8_t)j;
+                }
+            }
+        }
+    }
     __syncthreads();
     uint32_t my_nan = 0;
     const int64_t n4 = n >> 2;
@@ -46,10 +81,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__
         if (PASS == 0) {
             atomicAdd(&lh[k >> 21], 1u);
         } else {
-            const uint32_t p = PASS == 1 ? (k >> 21) : (k >> 10);
-            const uint32_t b = PASS == 1 ? ((k >> 10) & 2047u) : (k & 1023u);
-            for (int j = 0; j < nprefix; j++)
-                if (spre[j] == p) atomicAdd(&lh[j * SEL_BINS + b], 1u);
+            const uint32_t s1 = tab1[k >> 21];
+            if (s1 != SEL_NONE) {
+                if (PASS == 1) {
+                    atomicAdd(&lh[s1 * SEL_BINS + ((k >> 10) & 2047u)], 1u);
+                } else {
+                    const uint32_t s2 = tab2[(size_t)s1 * SEL_BINS + ((k >> 10) & 2047u)];
+                    if (s2 != SEL_NONE) atomicAdd(&lh[s2 * SEL_BINS + (k & 1023u)], 1u);
+                }
+            }
         }
     };
     for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SEL_THREADS) {
@@ -94,9 +134,10 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
     long long *h_hist = (long long *)ctx->h_pin;
 
     static bool attr_done = false;
+    const int SEL_BATCH = 8;  // live prefixes per launch: 8 * (8 KB counters + 2 KB lookup) + 2 KB of LDS
     if (!attr_done) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RSSEG_MAX_RANKS * SEL_BINS * 4));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RSSEG_MAX_RANKS * SEL_BINS * 4));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BATCH * SEL_BINS * 4 + SEL_BINS));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BATCH * SEL_BINS * 5 + SEL_BINS));
         attr_done = true;
     }
     int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, SEL_THREADS)));
@@ -128,15 +169,18 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
         }
         const size_t used = ((size_t)ndp * SEL_BINS) * sizeof(unsigned long long);
         HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_bytes, ctx->stream));
-        {
+        for (int b0 = 0; b0 < ndp; b0 += SEL_BATCH) {
             prof_scope ps(ctx, "select");
-            const size_t lds = (size_t)ndp * SEL_BINS * sizeof(uint32_t);
+            const int nb_ = std::min(SEL_BATCH, ndp - b0);
+            // counters + tab1 (+ tab2: at most nb_ distinct 11-bit prefixes)
+            const size_t lds = (size_t)nb_ * SEL_BINS * sizeof(uint32_t) + (pass == 0 ? 0 : SEL_BINS) + (pass == 2 ? (size_t)nb_ * SEL_BINS : 0);
+            unsigned long long *hb = d_hist + (size_t)b0 * SEL_BINS;
             if (pass == 0)
-                hipLaunchKernelGGL(k1_hist<0>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+                hipLaunchKernelGGL(k1_hist<0>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, 1, hb, d_nan);
             else if (pass == 1)
-                hipLaunchKernelGGL(k1_hist<1>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+                hipLaunchKernelGGL(k1_hist<1>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre + b0, nb_, hb, d_nan);
             else
-                hipLaunchKernelGGL(k1_hist<2>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, ndp, d_hist, d_nan);
+                hipLaunchKernelGGL(k1_hist<2>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre + b0, nb_, hb, d_nan);
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, pass == 0 ? hist_bytes : used, hipMemcpyDeviceToHost, ctx->stream));

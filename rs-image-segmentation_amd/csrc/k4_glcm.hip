@@ -6,19 +6,22 @@
 //
 // The co-occurrence matrix is never formed.  All five properties follow from exact integer
 // statistics of the window's pixel pairs (a, b), per angle:
-//     np = #pairs, S1 = sum|a-b|, S2 = sum(a-b)^2, Hq = sum round(2^52/(1+(a-b)^2)),
-//     M1 = sum(a+b), M2 = sum(a^2+b^2), Mx = sum 2ab,
-//     A  = sum_ij (G_ij+G_ji)^2 = 2*(np + 2*E_all) + 2*(D + 2*E_diag)
-//          E_all  = #{p<q : unordered(a_p,b_p) == unordered(a_q,b_q)},  D = #{p : a_p == b_p},
-//          E_diag = #{p<q : a_p == b_p == a_q == b_q}
+//     np = #pairs, S1 = sum|a-b|, XY = sum a*b, M1 = sum(a+b), M2 = sum(a^2+b^2),  S2 = M2 - 2 XY,
+//     Hq = sum round(2^52/(1+(a-b)^2)),
+//     A  = sum_ij (G_ij+G_ji)^2 = 2*(np + D) + 4*E2,  D = #{p : a_p == b_p},
+//          E2 = sum over runs of equal unordered keys of w*c(c-1)/2, w = 2 on the diagonal else 1
 // and the float64 formulas at the end are those of oracle.c (mode 1), so results are bit-identical.
+// Angles 0/90 (np = w(w-1)) and 45/135 (np = (w-1)^2) are combined over common denominators, which
+// leaves 8 float64 divisions and 4 square roots per window.
 //
 // Two kernels:
-//   k4_glcm_thread<WIN>  one thread per window, window in registers, pair statistics by direct
-//                        comparison (WIN <= 7; the dense step-1 case of BASELINE config 3).
-//                        Integer-VALU-bound: ~WIN^4 compare-accumulates per window and angle.
+//   k4_glcm_thread<WIN>  one thread per window (WIN <= 7, levels <= 64; the dense step-1 case of BASELINE
+//        config 3).  The window lives in 2*WIN registers, 4 pixels per register: pair moments come from
+//        v_sad_u8 / v_dot4_u32_u8 on whole rows; the unordered pair keys (13 bits) of TWO angles share a
+//        register and go through one Batcher network of v_pk_min_u16 / v_pk_max_u16, then a packed
+//        run-length pass.  Integer-VALU-bound, not HBM-bound (1 B/px in, 20 B/px out).
 //   k4_glcm_wg           one workgroup per window with an LDS co-occurrence histogram (any window
-//                        size, levels <= 64; the reference's 21x21 / step 21 default).
+//        size, levels <= 64; the reference's 21x21 / step 21 default).
 #include <utility>
 
 #include "common.h"
@@ -36,15 +39,36 @@ struct glcm_stats {
     long long np, S1, S2, Hq, M1, M2, Mx, A;
 };
 
-__device__ __forceinline__ void glcm_props(const glcm_stats &s, double &pc, double &pd, double &ph, double &pe, double &pr)
+// correlation of one angle from exact integers (oracle.c mode 1)
+__device__ __forceinline__ double glcm_corr(long long np, long long M1, long long M2, long long Mx)
 {
-    const double npd = (double)s.np, tot = (double)(2 * s.np);
-    pc = (double)s.S2 / npd;
-    pd = (double)s.S1 / npd;
-    ph = ((double)s.Hq * (1.0 / 4503599627370496.0)) / npd;
-    pe = sqrt((double)s.A / (tot * tot));
-    const long long den = s.M2 * (2 * s.np) - s.M1 * s.M1, num = s.Mx * (2 * s.np) - s.M1 * s.M1;
-    pr = den == 0 ? 1.0 : (double)num / (double)den;
+    const long long den = M2 * (2 * np) - M1 * M1, num = Mx * (2 * np) - M1 * M1;
+    return den == 0 ? 1.0 : (double)num / (double)den;
+}
+
+// group sums: g0 = angles 0 and 90 degrees (na pairs each), g1 = 45 and 135 degrees (nb pairs each)
+struct glcm_group {
+    long long S1, S2, Hq;
+    double sq;  // sqrt(A_a) + sqrt(A_b)
+};
+
+__device__ __forceinline__ void glcm_finish(const glcm_group &g0, const glcm_group &g1, long long na, long long nb, double r0,
+                                            double r1, double r2, double r3, size_t o, const glcm_out &out)
+{
+    const double dna = (double)na, dnb = (double)nb, den4 = (double)(4 * na * nb), den8 = (double)(8 * na * nb);
+    if (out.p[0]) out.p[0][o] = (float)((double)(g0.S2 * nb + g1.S2 * na) / den4);
+    if (out.p[1]) out.p[1][o] = (float)((double)(g0.S1 * nb + g1.S1 * na) / den4);
+    if (out.p[2]) {
+        const double t1 = (double)g1.Hq * dna;
+        const double num = fma((double)g0.Hq, dnb, t1);
+        out.p[2][o] = (float)((num / den4) * (1.0 / 4503599627370496.0));
+    }
+    if (out.p[3]) {
+        const double t1 = g1.sq * dna;
+        const double num = fma(g0.sq, dnb, t1);
+        out.p[3][o] = (float)(num / den8);
+    }
+    if (out.p[4]) out.p[4][o] = (float)((((r0 + r1) + r2) + r3) * 0.25);
 }
 
 // ---- compile-time machinery: every register array below is indexed by constants only ----------
@@ -80,80 +104,168 @@ template <int P> constexpr sort_net<P> make_sort_net()
     s.n = n;
     return s;
 }
-
 template <int P> struct net_holder {
     static constexpr sort_net<P> net = make_sort_net<P>();
 };
 
-template <int WIN, int A> struct angle_geom {
-    static constexpr int DR = A == 0 ? 0 : 1;
-    static constexpr int DC = A == 0 ? 1 : (A == 1 ? 1 : (A == 2 ? 0 : -1));
-    static constexpr int R1 = DR > 0 ? WIN - 1 : WIN;
-    static constexpr int C0 = DC < 0 ? 1 : 0;
-    static constexpr int C1 = DC > 0 ? WIN - 1 : WIN;
-    static constexpr int PW = C1 - C0;
-    static constexpr int P = R1 * PW;
-};
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ unsigned pk_shr12(unsigned a)
+{
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) >> (us2)(12)));
+}
 
-// pair statistics of one angle; key = diag<<16 | lo<<8 | hi, sorted, equal runs counted
-// window rows packed 4 pixels per register: w[r][0] = px 0..3, w[r][1] = px 4..7
+// window rows packed 4 pixels per register: w[r][0] = px 0..3, w[r][1] = px 4..7 (zero beyond WIN-1)
 template <int R, int C> __device__ __forceinline__ int px_at(const unsigned (&w)[8][2])
 {
     return (int)((w[R][C >> 2] >> (8 * (C & 3))) & 0xffu);
 }
 
-template <int WIN, int A>
-__device__ __forceinline__ void glcm_angle(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_stats &s)
+__device__ __forceinline__ void pin64(long long &v)
 {
-    using G = angle_geom<WIN, A>;
-    constexpr int P = G::P;
-    unsigned key[P];
-    unsigned S1 = 0;
-    int M1 = 0, M2 = 0, Mx = 0;
-    long long Hq = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+
+// 13-bit unordered pair key: diag << 12 | lo << 6 | hi   (levels <= 64)
+__device__ __forceinline__ unsigned pair_key(int x, int y, unsigned &d)
+{
+    const int lo = x < y ? x : y, hi = x < y ? y : x;
+    d = (unsigned)(hi - lo);
+    return ((unsigned)lo << 6) | (unsigned)hi | (d == 0 ? 4096u : 0u);
+}
+
+// pair moments of one angle from whole packed rows: S1 = sum|a-b|, XY = sum ab, M2 = sum a^2+b^2, M1 = sum a+b
+template <int WIN, int DR, int DC>
+__device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned &S1, unsigned &XY, unsigned &M2, unsigned &M1)
+{
+    constexpr int NB = DC == 0 ? WIN : WIN - 1;  // bytes taking part per row
+    constexpr unsigned KLO = NB >= 4 ? 0xffffffffu : ((1u << (8 * (NB & 3))) - 1u);
+    constexpr unsigned KHI = NB <= 4 ? 0u : ((NB >= 8) ? 0xffffffffu : ((1u << (8 * (NB - 4))) - 1u));
+    constexpr int R1 = DR > 0 ? WIN - 1 : WIN;
+    S1 = XY = M2 = M1 = 0;
+    static_for<R1>([&](auto I) {
+        constexpr int r = I;
+        const unsigned a0 = w[r][0], a1 = w[r][1], b0 = w[r + DR][0], b1 = w[r + DR][1];
+        unsigned Alo, Ahi, Blo, Bhi;
+        if constexpr (DC == 1) {         // (c, c+1): A = bytes 0..WIN-2, B = bytes 1..WIN-1
+            Alo = a0 & KLO; Ahi = a1 & KHI;
+            Blo = __builtin_amdgcn_alignbyte(b1, b0, 1); Bhi = b1 >> 8;
+        } else if constexpr (DC == 0) {
+            Alo = a0; Ahi = a1; Blo = b0; Bhi = b1;
+        } else {                         // (c, c-1): A = bytes 1..WIN-1 of row r, B = bytes 0..WIN-2 of row r+1
+            Alo = __builtin_amdgcn_alignbyte(a1, a0, 1); Ahi = a1 >> 8;
+            Blo = b0 & KLO; Bhi = b1 & KHI;
+        }
+        S1 = __builtin_amdgcn_sad_u8(Alo, Blo, S1);
+        XY = __builtin_amdgcn_udot4(Alo, Blo, XY, false);
+        M2 = __builtin_amdgcn_udot4(Alo, Alo, M2, false);
+        M2 = __builtin_amdgcn_udot4(Blo, Blo, M2, false);
+        M1 = __builtin_amdgcn_sad_u8(Alo, 0u, M1);
+        M1 = __builtin_amdgcn_sad_u8(Blo, 0u, M1);
+        if constexpr (WIN > 4) {
+            S1 = __builtin_amdgcn_sad_u8(Ahi, Bhi, S1);
+            XY = __builtin_amdgcn_udot4(Ahi, Bhi, XY, false);
+            M2 = __builtin_amdgcn_udot4(Ahi, Ahi, M2, false);
+            M2 = __builtin_amdgcn_udot4(Bhi, Bhi, M2, false);
+            M1 = __builtin_amdgcn_sad_u8(Ahi, 0u, M1);
+            M1 = __builtin_amdgcn_sad_u8(Bhi, 0u, M1);
+        }
+    });
+}
+
+// One angle group: G = 0 -> angles 0 (0,1) and 90 (1,0) degrees, G = 1 -> 45 (1,1) and 135 (1,-1).
+// Both angles of a group have the same pair count P, so their keys share registers (low / high half).
+template <int WIN, int G>
+__device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_group &g,
+                                                 double &ra, double &rb)
+{
+    constexpr int P = G == 0 ? WIN * (WIN - 1) : (WIN - 1) * (WIN - 1);
+    unsigned K[P];
+    long long HqA = 0, HqB = 0;
     static_for<P>([&](auto I) {
         constexpr int p = I;
-        constexpr int r = p / G::PW, c = G::C0 + p % G::PW;
-        const int x = px_at<r, c>(w), y = px_at<r + G::DR, c + G::DC>(w);
-        const int lo = x < y ? x : y, hi = x < y ? y : x;
-        const unsigned d = (unsigned)(hi - lo);
-        key[p] = ((d == 0 ? 1u : 0u) << 16) | ((unsigned)lo << 8) | (unsigned)hi;
-        S1 += d;
-        Hq += hq[d];
-        M1 += x + y;
-        M2 += x * x + y * y;
-        Mx += 2 * x * y;
-        // keep at most 8 LUT reads in flight: unconstrained, the scheduler issues all P of them up front
-        // and their 2P result registers push the kernel to one wave per SIMD
-        if constexpr (p % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        int xa, ya, xb, yb;
+        if constexpr (G == 0) {
+            constexpr int ra_ = p / (WIN - 1), ca_ = p % (WIN - 1);  // (r,c)-(r,c+1)
+            constexpr int rb_ = p / WIN, cb_ = p % WIN;              // (r,c)-(r+1,c)
+            xa = px_at<ra_, ca_>(w); ya = px_at<ra_, ca_ + 1>(w);
+            xb = px_at<rb_, cb_>(w); yb = px_at<rb_ + 1, cb_>(w);
+        } else {
+            constexpr int r_ = p / (WIN - 1), c_ = p % (WIN - 1);
+            xa = px_at<r_, c_>(w); ya = px_at<r_ + 1, c_ + 1>(w);    // (r,c)-(r+1,c+1)
+            xb = px_at<r_, c_ + 1>(w); yb = px_at<r_ + 1, c_>(w);    // (r,c+1)-(r+1,c)
+        }
+        unsigned da, db;
+        const unsigned ka = pair_key(xa, ya, da), kb = pair_key(xb, yb, db);
+        K[p] = ka | (kb << 16);
+        HqA += hq[da];
+        HqB += hq[db];
+        // pin the two accumulation chains: left alone, the optimiser re-associates the 2P integer adds into
+        // a tree, which keeps all 2P 64-bit LUT values alive at once (4P registers -> one wave per SIMD)
+        pin64(HqA);
+        pin64(HqB);
     });
+    unsigned S1a, XYa, M2a, M1a, S1b, XYb, M2b, M1b;
+    if constexpr (G == 0) {
+        row_moments<WIN, 0, 1>(w, S1a, XYa, M2a, M1a);
+        row_moments<WIN, 1, 0>(w, S1b, XYb, M2b, M1b);
+    } else {
+        row_moments<WIN, 1, 1>(w, S1a, XYa, M2a, M1a);
+        row_moments<WIN, 1, -1>(w, S1b, XYb, M2b, M1b);
+    }
+    // sort both halves at once
     static_for<net_holder<P>::net.n>([&](auto I) {
         constexpr int ia = net_holder<P>::net.a[I], ib = net_holder<P>::net.b[I];
-        const unsigned ka = key[ia], kb = key[ib];
-        key[ia] = ka < kb ? ka : kb;
-        key[ib] = ka < kb ? kb : ka;
+        const unsigned ka = K[ia], kb = K[ib];
+        K[ia] = pk_min(ka, kb);
+        K[ib] = pk_max(ka, kb);
     });
-    // E2 = sum over equal runs of w * c(c-1)/2 with w = 2 on the diagonal, 1 elsewhere
-    unsigned E2 = 0, t = 0, D = key[0] >> 16;
+    // packed run-length: t = equal-to-previous ? t + w : 0 ; E2 += t ; D += diag   (all < 2^16)
+    const unsigned one = 0x00010001u;
+    unsigned E2 = 0, t = 0, D = pk_shr12(K[0]);
     static_for<P - 1>([&](auto I) {
         constexpr int i = I + 1;
-        const unsigned w = 1u + (key[i] >> 16);
-        t = key[i] == key[i - 1] ? t + w : 0u;
-        E2 += t;
-        D += key[i] >> 16;
+        const unsigned diag = pk_shr12(K[i]);
+        const unsigned ne = pk_min(K[i] ^ K[i - 1], one);  // 0 where equal, 1 where different
+        const unsigned eq = pk_sub(one, ne);
+        t = pk_mul(pk_add(t, pk_add(diag, one)), eq);
+        E2 = pk_add(E2, t);
+        D = pk_add(D, diag);
     });
-    s.np = P;
-    s.S1 = S1;
-    s.S2 = (long long)M2 - (long long)Mx;  // sum (a-b)^2 = sum(a^2+b^2) - sum 2ab
-    s.Hq = Hq;
-    s.M1 = M1;
-    s.M2 = M2;
-    s.Mx = Mx;
-    s.A = 2ll * (P + (int)D) + 4ll * (long long)E2;
+    const long long Aa = 2ll * (P + (int)(D & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
+    const long long Ab = 2ll * (P + (int)(D >> 16)) + 4ll * (long long)(E2 >> 16);
+    g.S1 = (long long)S1a + (long long)S1b;
+    g.S2 = ((long long)M2a - 2ll * XYa) + ((long long)M2b - 2ll * XYb);
+    g.Hq = HqA + HqB;
+    g.sq = sqrt((double)Aa) + sqrt((double)Ab);
+    ra = glcm_corr(P, M1a, M2a, 2ll * XYa);
+    rb = glcm_corr(P, M1b, M2b, 2ll * XYb);
 }
 
 // compiler fence: the packed window is redefined (as far as the compiler can tell) at the top of every
-// angle iteration, so the four angle bodies cannot be hoisted out of the loop or merged
+// group iteration, so the two group bodies cannot be hoisted out of the loop or merged (their combined
+// live ranges would not fit the register budget)
 template <int WIN> __device__ __forceinline__ void opaque_window(unsigned (&w)[8][2])
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -191,30 +303,15 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
             w[r][1] = hi;
         });
     }
-    // The four angles run through a RUNTIME loop on purpose: unrolled, the compiler merges their common
-    // sub-expressions and the combined live ranges (4 x ~42 keys + 49 pixels) spill to scratch.
-    double sc = 0, sd = 0, sh = 0, se = 0, sr = 0;
+    glcm_group g0, g1;
+    double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0;
 #pragma nounroll
-    for (int a = 0; a < 4; a++) {
-        opaque_window<WIN>(w);  // the angle bodies are loop-invariant: without this they are all hoisted
-        glcm_stats s;
-        switch (a) {
-        case 0: glcm_angle<WIN, 0>(w, hq, s); break;
-        case 1: glcm_angle<WIN, 1>(w, hq, s); break;
-        case 2: glcm_angle<WIN, 2>(w, hq, s); break;
-        default: glcm_angle<WIN, 3>(w, hq, s); break;
-        }
-        double c, d, h, e, r;
-        glcm_props(s, c, d, h, e, r);
-        // (((p0 + p1) + p2) + p3): adding to an exact 0.0 first does not change p0
-        sc = sc + c; sd = sd + d; sh = sh + h; se = se + e; sr = sr + r;
+    for (int g = 0; g < 2; g++) {
+        opaque_window<WIN>(w);
+        if (g == 0) glcm_group_stats<WIN, 0>(w, hq, g0, r0, r2);
+        else glcm_group_stats<WIN, 1>(w, hq, g1, r1, r3);
     }
-    const size_t o = (size_t)oy * ow + ox;
-    if (out.p[0]) out.p[0][o] = (float)(sc / 4.0);
-    if (out.p[1]) out.p[1][o] = (float)(sd / 4.0);
-    if (out.p[2]) out.p[2][o] = (float)(sh / 4.0);
-    if (out.p[3]) out.p[3][o] = (float)(se / 4.0);
-    if (out.p[4]) out.p[4][o] = (float)(sr / 4.0);
+    glcm_finish(g0, g1, (long long)WIN * (WIN - 1), (long long)(WIN - 1) * (WIN - 1), r0, r1, r2, r3, (size_t)oy * ow + ox, out);
 }
 
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
@@ -223,7 +320,7 @@ __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q,
 {
     extern __shared__ unsigned int hist[];  // levels*levels
     __shared__ long long red[4][8];
-    __shared__ double props[4][5];
+    __shared__ long long sst[4][8];
     const int ox = blockIdx.x, oy = blockIdx.y;
     const uint8_t *wp = q + (size_t)(oy * step) * W + (size_t)ox * step;
     const int LL = levels * levels;
@@ -237,7 +334,6 @@ __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q,
         for (int p = threadIdx.x; p < P; p += 256) {
             const int r = p / pw, c = c0 + p % pw;
             const int x = wp[(size_t)r * W + c], y = wp[(size_t)(r + dr) * W + (c + dc)];
-            if (x >= levels || y >= levels) continue;
             atomicAdd(&hist[x * levels + y], 1u);
             const int d = x > y ? x - y : y - x;
             st[0] += 1; st[1] += d; st[2] += d * d; st[3] += c_glcm_hq[d];
@@ -255,22 +351,20 @@ __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q,
             if (lane_id() == 0) red[threadIdx.x >> 6][t] = s;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            glcm_stats s;
-            long long *sp = &s.np;
-            for (int t = 0; t < 8; t++) sp[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-            if (s.np == 0) {
-                props[a][0] = props[a][1] = props[a][2] = props[a][3] = 0.0;
-                props[a][4] = 1.0;
-            } else {
-                glcm_props(s, props[a][0], props[a][1], props[a][2], props[a][3], props[a][4]);
-            }
-        }
+        if (threadIdx.x < 8) sst[a][threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         __syncthreads();
     }
-    if (threadIdx.x < 5 && out.p[threadIdx.x]) {
-        const int t = threadIdx.x;
-        out.p[t][(size_t)oy * ow + ox] = (float)((((props[0][t] + props[1][t]) + props[2][t]) + props[3][t]) / 4.0);
+    if (threadIdx.x == 0) {
+        // sst[a] = np S1 S2 Hq M1 M2 Mx A ; all pixels are < levels, so np depends on the geometry only
+        glcm_group g0, g1;
+        g0.S1 = sst[0][1] + sst[2][1]; g0.S2 = sst[0][2] + sst[2][2]; g0.Hq = sst[0][3] + sst[2][3];
+        g0.sq = sqrt((double)sst[0][7]) + sqrt((double)sst[2][7]);
+        g1.S1 = sst[1][1] + sst[3][1]; g1.S2 = sst[1][2] + sst[3][2]; g1.Hq = sst[1][3] + sst[3][3];
+        g1.sq = sqrt((double)sst[1][7]) + sqrt((double)sst[3][7]);
+        double r[4];
+        for (int a = 0; a < 4; a++) r[a] = glcm_corr(sst[a][0], sst[a][4], sst[a][5], sst[a][6]);
+        glcm_finish(g0, g1, (long long)win * (win - 1), (long long)(win - 1) * (win - 1), r[0], r[1], r[2], r[3],
+                    (size_t)oy * ow + ox, out);
     }
 }
 
@@ -295,6 +389,7 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
     {
         prof_scope ps(ctx, "glcm");
         const dim3 tg((ow + 63) / 64, (oh + 3) / 4);
+        if (levels > 64) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: levels > 64 not supported");
         if (win == 7)
             hipLaunchKernelGGL(k4_glcm_thread<7>, tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out);
         else if (win == 5)
@@ -302,7 +397,6 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         else if (win == 3)
             hipLaunchKernelGGL(k4_glcm_thread<3>, tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out);
         else {
-            if (levels > 64) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: levels > 64 with window %d not supported", win);
             if (ow > 2147483647 || oh > 65535) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: output map too tall for the workgroup-per-window kernel");
             hipLaunchKernelGGL(k4_glcm_wg, dim3(ow, oh), dim3(256), sizeof(unsigned int) * levels * levels, ctx->stream, d_q, H, W,
                                levels, win, step, oh, ow, out);

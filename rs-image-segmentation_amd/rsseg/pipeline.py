@@ -28,6 +28,44 @@ def band_lohi(ctx: Context, bands: Sequence, n_global: Optional[int] = None) -> 
     return out
 
 
+def band_quantile_bundle(ctx: Context, band, n_global: Optional[int] = None):
+    """Everything the stage needs from ONE band's order statistics, with ONE select (3 passes over the plane):
+      lo, hi          np.percentile(band, 2 / 98)                      (robust_normalize, indices.py:38-39)
+      center, scale   RobustScaler statistics of the NORMALISED band  (indices.py:230-231)
+      lo2, hi2        np.percentile(normalised band, 2 / 98)         (the texture functions re-normalise, :265)
+    The normalisation f(v) = (clip(v, lo, hi) - lo) / (hi - lo + 1e-10) is monotone non-decreasing in float32
+    arithmetic, so the k-th smallest normalised value is f(k-th smallest raw value): the quantiles of the
+    normalised band follow from the raw band's order statistics pushed through f on the host (same float32
+    operations as the K2 kernel).  Falls back to separate selects when the band holds NaNs."""
+    from .quantiles import median_plan, percentile_plan, robust_scaler_stats
+    n = int(band.numel()) if n_global is None else int(n_global)
+    p2r, p2f = percentile_plan(n, 2, np.float32, True)
+    p98r, p98f = percentile_plan(n, 98, np.float32, True)
+    mr, mf = median_plan(n, np.float32)
+    qr, qf = percentile_plan(n, (25.0, 75.0), np.float32, False)
+    vals, n_nan = ctx.order_stats(band, p2r + p98r + mr + qr)
+    if n_nan > 0:
+        lo, hi = band_percentiles(ctx, band, (2, 98), n_global)
+        return dict(lo=lo, hi=hi, center=None, scale=None, lo2=None, hi2=None)
+    o = 0
+    parts = []
+    for r in (p2r, p98r, mr, qr):
+        parts.append(vals[o:o + len(r)])
+        o += len(r)
+    lo, hi = p2f(parts[0]), p98f(parts[1])
+    den = hi - lo + 1e-10  # float32, as in robust_normalize
+
+    def f(v):
+        return (np.clip(v, lo, hi) - lo) / den
+
+    center = np.float32(mf(f(parts[2])))
+    q = qf(f(parts[3]))
+    scale = np.float64(q[1] - q[0])
+    if scale < 10 * np.finfo(np.float64).eps:
+        scale = np.float64(1.0)
+    return dict(lo=lo, hi=hi, center=center, scale=scale, lo2=p2f(f(parts[0])), hi2=p98f(f(parts[1])))
+
+
 def normalize_bands(ctx: Context, bands: Sequence, lohi: np.ndarray) -> List:
     return [ctx.normalize(b, float(lohi[i, 0]), float(lohi[i, 1])) for i, b in enumerate(bands)]
 
@@ -40,12 +78,14 @@ def spectral_indices(ctx: Context, bands: Sequence, lohi: Optional[np.ndarray], 
 
 
 def pca(ctx: Context, norm_bands: Sequence, n_components: Optional[int] = None, use_robust_scaling: bool = True,
-        n_global: Optional[int] = None):
-    """perform_pca (indices.py:205-246) on normalised band planes."""
+        n_global: Optional[int] = None, stats=None):
+    """perform_pca (indices.py:205-246) on normalised band planes.  `stats` (optional): precomputed
+    [(center, scale)] per band from band_quantile_bundle."""
     nb = len(norm_bands)
     nc = nb if n_components is None else n_components
     if use_robust_scaling:
-        stats = [robust_scaler_stats(ctx, b, n_global) for b in norm_bands]
+        if stats is None:
+            stats = [robust_scaler_stats(ctx, b, n_global) for b in norm_bands]
         center = np.array([s[0] for s in stats], np.float32)
         scale = np.array([s[1] for s in stats], np.float64)
     else:
@@ -109,15 +149,23 @@ def config2(ctx: Context, bands: Sequence, k: int = 6):
     return labels, meta, planes
 
 
-def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3):
+def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3,
+            n_global: Optional[int] = None):
     """BASELINE config 3: 7 indices + 5 GLCM properties (window 7, 4 angles) + PCA(3) -> 15 float32
-    features -> KMeans(k)."""
-    lohi = band_lohi(ctx, bands)
+    features -> KMeans(k).  One select per band serves all percentile requests (band_quantile_bundle)."""
+    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
-    pcs, ratio, model = pca(ctx, norm_all, n_pca, True)
-    nir2 = renormalize(ctx, norm_all[3])
-    del norm_all
+    if all(q["center"] is not None for q in qb):
+        stats = [(q["center"], q["scale"]) for q in qb]
+        lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
+    else:
+        stats = None
+        lo2, hi2 = band_percentiles(ctx, norm_all[3], (2, 98), n_global)
+    pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, stats)
+    nir2 = ctx.normalize(norm_all[3], float(lo2), float(hi2))
+    del norm_all, norms
     glcm, _ = glcm_features(ctx, nir2, H, W, 32, glcm_window, glcm_step)
     planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)

@@ -380,3 +380,55 @@ def test_forest_deep_synthetic_vs_oracle(ctx, oracle):
     ctx.forest_load(f)
     got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(19)]))
     assert np.array_equal(got, want)
+
+
+def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
+    """One select per band (config-3 fast path) gives the same six statistics as the separate NumPy-style
+    calls on the raw and on the normalised band."""
+    from rsseg import pipeline as P
+    from rsseg.quantiles import band_percentiles, robust_scaler_stats
+    bands = oracle.stage1_preprocess(scene["dn"])
+    for b in (bands[0], bands[3], bands[6]):
+        d = dev(ctx, b)
+        q = P.band_quantile_bundle(ctx, d)
+        lo, hi = band_percentiles(ctx, d, (2, 98))
+        assert q["lo"] == lo and q["hi"] == hi
+        nd = ctx.normalize(d, float(lo), float(hi))
+        c, s = robust_scaler_stats(ctx, nd)
+        assert q["center"] == c and q["scale"] == s
+        lo2, hi2 = band_percentiles(ctx, nd, (2, 98))
+        assert q["lo2"] == lo2 and q["hi2"] == hi2
+        nb = oracle.robust_normalize(b)
+        assert q["lo2"] == np.percentile(nb, 2) and q["hi2"] == np.percentile(nb, 98)
+    # NaN band: falls back
+    x = bands[1].copy()
+    x[3, 4] = np.nan
+    q = P.band_quantile_bundle(ctx, dev(ctx, x))
+    assert np.isnan(q["lo"]) and q["center"] is None
+
+
+def test_config3_pipeline_vs_oracle(ctx, oracle):
+    """BASELINE config 3 on a 192 x 160 synthetic tile: features and labels against the CPU oracle."""
+    from rsseg import pipeline as P
+    H, W = 192, 160
+    r = oracle.synthetic_raster(H, W)
+    labels, meta, planes = P.config3(ctx, [dev(ctx, r[i]) for i in range(7)], H, W, 8, 7, 1, 3)
+    norm = [oracle.robust_normalize(r[i]) for i in range(7)]
+    b, g, rd, n, s = norm[:5]
+    feats = [oracle.calculate_ndvi(n, rd), oracle.calculate_evi(n, rd, b), oracle.calculate_msavi(n, rd),
+             oracle.calculate_ndwi(g, n), oracle.calculate_mndwi(g, s), oracle.calculate_ndbi(s, n),
+             oracle.calculate_bsi(b, rd, n, s)]
+    gl, _ = oracle.calculate_glcm_features(norm[3], 32, 7, 1)
+    feats += [gl[x] for x in ("contrast", "dissimilarity", "homogeneity", "energy", "correlation")]
+    for i in range(12):
+        assert np.array_equal(host(planes[i], (H, W)), feats[i]), i
+    truth, _ = _pca_truth64(norm)  # float64 evaluation; the float32 CPU path carries ~1e-5 BLAS noise itself
+    pcs, _, _ = oracle.perform_pca(norm, n_components=3)
+    for i in range(3):
+        got = host(planes[12 + i], (H, W))
+        assert np.abs(got - truth[i].reshape(H, W)).max() <= 1e-5
+        assert np.abs(got - pcs[i]).max() <= 1e-4
+    # labels: bit-exact against the oracle KMeans run on the GPU's own feature planes
+    want, info = oracle.kmeans_fit_planes([host(p, (H, W)) for p in planes], 8)
+    assert meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(host(labels), want)
