@@ -226,6 +226,7 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         pin64(HqA);
         pin64(HqB);
     });
+    __builtin_amdgcn_sched_barrier(0);  // phase boundaries keep the phases' live ranges from overlapping
     unsigned S1a, XYa, M2a, M1a, S1b, XYb, M2b, M1b;
     if constexpr (G == 0) {
         row_moments<WIN, 0, 1>(w, S1a, XYa, M2a, M1a);
@@ -234,6 +235,7 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         row_moments<WIN, 1, 1>(w, S1a, XYa, M2a, M1a);
         row_moments<WIN, 1, -1>(w, S1b, XYb, M2b, M1b);
     }
+    __builtin_amdgcn_sched_barrier(0);
     // sort both halves at once
     static_for<net_holder<P>::net.n>([&](auto I) {
         constexpr int ia = net_holder<P>::net.a[I], ib = net_holder<P>::net.b[I];
@@ -241,6 +243,7 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         K[ia] = pk_min(ka, kb);
         K[ib] = pk_max(ka, kb);
     });
+    __builtin_amdgcn_sched_barrier(0);
     // packed run-length: t = equal-to-previous ? t + w : 0 ; E2 += t ; D += diag   (all < 2^16)
     const unsigned one = 0x00010001u;
     unsigned E2 = 0, t = 0, D = pk_shr12(K[0]);

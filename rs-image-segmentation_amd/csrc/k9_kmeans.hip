@@ -469,6 +469,90 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// _relocate_empty_clusters_dense (sklearn/cluster/_k_means_common.pyx:167-211), device part: the pixel
+// farthest from the OLD centre of its label, distance = ((X - centers_old[labels])**2).sum(axis=1) in T
+// with NumPy's pairwise summation order over the F columns; ties -> lowest pixel index; pixels whose
+// global index is in `taken` are skipped.  One (distance, index) pair per chunk; the host finishes.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int FR>
+__device__ __forceinline__ T np_pairwise_sum_dev(const T (&a)[FR], int n)
+{
+    if (n < 8) {
+        T res = (T)0;
+#pragma unroll
+        for (int i = 0; i < 8 && i < FR; i++)
+            if (i < n) res = res + a[i];
+        return res;
+    }
+    T r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = a[j < FR ? j : 0];
+    const int nb = n / 8;
+#pragma unroll
+    for (int b = 1; b < FR / 8; b++)
+        if (b < nb) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = r[j] + a[b * 8 + j];
+        }
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = 8; i < FR; i++)
+        if (i >= nb * 8 && i < n) res = res + a[i];
+    return res;
+}
+
+struct taken_t {
+    long long idx[RSSEG_MAX_CLUSTERS];
+    int n;
+};
+
+template <typename T, int KMAX, int FR>
+__global__ __launch_bounds__(KM_THREADS) void km_farthest(planes_t pl, int F, int64_t n, int64_t offset,
+                                                          const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
+                                                          const uint8_t *__restrict__ labels, taken_t taken,
+                                                          T *__restrict__ pdist, long long *__restrict__ pidx)
+{
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    T best = (T)-1;
+    long long bidx = 0x7fffffffffffffffLL;
+    for (int64_t i = chunk0 + threadIdx.x; i < chunk0 + km_chunk<T>() && i < n; i += KM_THREADS) {
+        bool skip = false;
+        for (int t = 0; t < taken.n; t++) skip = skip || taken.idx[t] == offset + i;
+        if (skip) continue;
+        const int lab = labels[i];
+        T dd[FR];
+#pragma unroll
+        for (int f = 0; f < FR; f++) {
+            if (f < F) {
+                const T x = scaled<T>(reinterpret_cast<const T *>(pl.p[f])[i], sp->scale[f], sp->minv[f]) - sp->mean[f];
+                const T t = x - cenT[f * KMAX + lab];
+                dd[f] = t * t;
+            } else {
+                dd[f] = (T)0;
+            }
+        }
+        const T d = np_pairwise_sum_dev<T, FR>(dd, F);
+        if (d > best) { best = d; bidx = offset + i; }  // ascending i within a thread: first max kept
+    }
+    // (max distance, min index) over the workgroup
+    for (int o = 32; o > 0; o >>= 1) {
+        const T ob = __shfl_xor(best, o, 64);
+        const long long oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    __shared__ T sb[4];
+    __shared__ long long si[4];
+    if (lane_id() == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (sb[w] > best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
+        pdist[blockIdx.x] = best;
+        pidx[blockIdx.x] = bidx;
+    }
+}
+
 // column sums of partial[M][nchunks] -> out[M][2] = {sum of (v >> 32), sum of (v & 0xffffffff)}
 __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__restrict__ partial, int64_t nchunks,
                                                             long long *__restrict__ out)
@@ -685,6 +769,15 @@ void launch_kpp(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, 
     if (L <= 1) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
     else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
     else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+}
+
+template <typename T, int KMAX>
+void launch_farthest(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, int64_t offset, const scaler_t<T> *sp,
+                     const T *cenT, const uint8_t *labels, const taken_t &tk, T *pdist, long long *pidx)
+{
+    if (F <= 8) hipLaunchKernelGGL((km_farthest<T, KMAX, 8>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
+    else if (F <= 16) hipLaunchKernelGGL((km_farthest<T, KMAX, 16>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
+    else hipLaunchKernelGGL((km_farthest<T, KMAX, 32>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
 }
 
 template <typename T>
@@ -1078,20 +1171,84 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             if (cnt[j] == 0) n_empty++;
         }
         const int64_t changed = (int64_t)limbs(red[2 * (KMAX * F + KMAX)], red[2 * (KMAX * F + KMAX) + 1]);
-        if (n_empty > 0)
-            return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED,
-                           "kmeans: %d empty cluster(s) at iteration %d — relocation (_relocate_empty_clusters_dense) not implemented yet",
-                           n_empty, it);
+        // exact per-cluster sums as 128-bit integers
+        i128 S[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+        for (int j = 0; j < k; j++)
+            for (int f = 0; f < F; f++) S[j][f] = limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]);
+        if (n_empty > 0) {
+            // _relocate_empty_clusters_dense: the e-th empty cluster takes the e-th farthest pixel
+            taken_t tk;
+            tk.n = 0;
+            T dmax_all = (T)0;
+            int e = 0;
+            for (int j = 0; j < k && e < n_empty; j++) {
+                if (cnt[j] != 0) continue;
+                double best[2] = {-1.0, 0.0};
+                long long bidx = 0x7fffffffffffffffLL;
+                if (n > 0) {
+                    T *pd = (T *)d_part;
+                    long long *pi = d_part + nchunks;  // after the distances (sizeof(T) <= 8)
+                    switch (KMAX) {
+                    case 8: launch_farthest<T, 8>(ctx, nchunks, pl, F, n, offset, d_sp, d_cen, d_lab, tk, pd, pi); break;
+                    case 16: launch_farthest<T, 16>(ctx, nchunks, pl, F, n, offset, d_sp, d_cen, d_lab, tk, pd, pi); break;
+                    case 32: launch_farthest<T, 32>(ctx, nchunks, pl, F, n, offset, d_sp, d_cen, d_lab, tk, pd, pi); break;
+                    default: launch_farthest<T, 64>(ctx, nchunks, pl, F, n, offset, d_sp, d_cen, d_lab, tk, pd, pi); break;
+                    }
+                    HIPCHK(ctx, hipGetLastError());
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * 2 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
+                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    const T *hd = (const T *)ctx->h_pin;
+                    const long long *hi = (const long long *)ctx->h_pin + nchunks;
+                    for (int64_t c2 = 0; c2 < nchunks; c2++)
+                        if ((double)hd[c2] > best[0] || ((double)hd[c2] == best[0] && hi[c2] < bidx)) { best[0] = (double)hd[c2]; bidx = hi[c2]; }
+                }
+                double gmax = best[0];
+                RSCHK(comm_allreduce_host(ctx, &gmax, 1, RSSEG_F64, RSSEG_MAX));
+                double gidx = (best[0] == gmax && bidx != 0x7fffffffffffffffLL) ? (double)bidx : 9.0e18;
+                RSCHK(comm_allreduce_host(ctx, &gidx, 1, RSSEG_F64, RSSEG_MIN));
+                if (e == 0) dmax_all = (T)gmax;
+                if (dmax_all == (T)0 || gidx >= 9.0e18) break;  // np.max(distances) == 0: relocation is pointless
+                const int64_t far = (int64_t)gidx;
+                tk.idx[tk.n++] = far;
+                T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
+                RSCHK(fetch_rows(&far, 1, rows));
+                double oldlab = 0.0;
+                if (far >= offset && far < offset + n) {
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lab + (far - offset), 1, hipMemcpyDeviceToHost, st));
+                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    oldlab = (double)((const uint8_t *)ctx->h_pin)[0];
+                }
+                RSCHK(comm_allreduce_host(ctx, &oldlab, 1, RSSEG_F64, RSSEG_SUM));
+                const int oj = (int)oldlab;
+                for (int f = 0; f < F; f++) {
+                    const i128 q = (i128)llrint((double)rows[0][f] * 1099511627776.0);
+                    S[oj][f] -= q;
+                    S[j][f] = q;
+                }
+                cnt[j] = 1;
+                cnt[oj] -= 1;
+                relocated++;
+                e++;
+            }
+        }
+        // _average_centers
         T Cnew[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+        int argmax_w = 0;
+        for (int j = 1; j < k; j++)
+            if (cnt[j] > cnt[argmax_w]) argmax_w = j;
         for (int j = 0; j < k; j++) {
+            if (cnt[j] <= 0) continue;
             volatile T w = (T)cnt[j];
             volatile T alpha = (T)(1.0 / (double)w);
             for (int f = 0; f < F; f++) {
-                volatile T s = fixed_to_T<T>(limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]));
-                volatile T cnew = s * alpha;
+                volatile T sT = fixed_to_T<T>(S[j][f]);
+                volatile T cnew = sT * alpha;
                 Cnew[j][f] = cnew;
             }
         }
+        for (int j = 0; j < k; j++)
+            if (cnt[j] <= 0)
+                for (int f = 0; f < F; f++) Cnew[j][f] = Cnew[argmax_w][f];
         T shift2[RSSEG_MAX_CLUSTERS];
         for (int j = 0; j < k; j++) {
             const T *a = Cnew[j], *b = C[j];

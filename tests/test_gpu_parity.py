@@ -432,3 +432,29 @@ def test_config3_pipeline_vs_oracle(ctx, oracle):
     want, info = oracle.kmeans_fit_planes([host(p, (H, W)) for p in planes], 8)
     assert meta["n_iter"] == info["n_iter"]
     assert np.array_equal(host(labels), want)
+
+
+@pytest.mark.parametrize("seed", [20, 22, 25, 26, 29, 30])
+def test_kmeans_empty_cluster_relocation(ctx, oracle, seed):
+    """Duplicate-heavy data with more clusters than distinct points: clusters run empty and are re-seeded
+    with the farthest pixels (_relocate_empty_clusters_dense).  GPU == oracle bit for bit (and the oracle
+    equals scikit-learn on these inputs, oracle/gen_golden-style check in the docstring of DESIGN.md §4)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(20, 120)); F = int(rng.integers(1, 4)); k = int(rng.integers(6, 14))
+    X = rng.random((n, F)).astype(np.float32)
+    X = (np.round(X * rng.integers(2, 6)) / 4.0).astype(np.float32)
+    planes = [np.ascontiguousarray(X[:, f]) for f in range(F)]
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    assert info["relocated"] > 0
+    labels, meta = ctx.kmeans_fit_predict([dev(ctx, p) for p in planes], k)
+    assert meta["relocated"] == info["relocated"]
+    assert meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(host(labels), want)
+    from sklearn.cluster import KMeans
+    from sklearn.preprocessing import MinMaxScaler
+    from threadpoolctl import threadpool_limits
+    import warnings
+    with threadpool_limits(limits=1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = KMeans(n_clusters=k, random_state=42, n_init="auto").fit_predict(MinMaxScaler().fit_transform(X))
+    assert np.array_equal(host(labels), ref)
