@@ -6,62 +6,118 @@
 // RandomForestClassifier.predict: sklearn/ensemble/_forest.py:640 (float32 cast), 903-906, 948-962;
 // Tree._apply_dense sklearn/tree/_tree.pyx:955-996.
 //
-// Forest layout in HBM: 16-byte nodes {float thr, int feature, int left, int right|missing<<31}.
+// Forest layout (built once by rsseg_forest_load): every tree is renumbered in BREADTH-FIRST order, so
+//   * the two children of a node are adjacent (left = c, right = c + 1): a node is 8 bytes
+//       { float thr ; uint32 : bits 0-23 left child (or leaf-value row), 24-29 feature, 30 missing->left, 31 leaf }
+//   * the first NTOP nodes of a tree are its upper levels: the workgroup copies that block into LDS
+//     (double-buffered, the copy of tree t+1 overlaps the walk of tree t) and only the levels below it
+//     are gathered from L2 / Infinity Cache.
 // `X[i,f] <= threshold` compares a float32 feature with a float64 threshold; that is equivalent to
-// comparing with the threshold rounded DOWN to float32, which is what thr holds.  Leaves have
-// feature = -1 and left = row of the (n_leaves x n_classes) float64 value table.
-// The pixel's features are staged once in LDS ([F][256] floats, bank = lane, conflict-free for any
-// per-lane feature choice); nodes are read through L1/L2 (the forest is small against the 4 MiB L2
-// for shallow forests, Infinity-Cache resident for depth-16 forests).  Gather-latency-bound, not
-// HBM-bound: algorithmic HBM traffic is 4F B/px in + 8 B/px out.
+// comparing with the threshold rounded DOWN to float32, which is what thr holds.
+// The pixel's features are staged once in LDS ([F][1024] floats, bank = lane, conflict-free for any
+// per-lane feature choice).  A leaf whose value row is one-hot carries its class in the node (no gather).
+// Gather-latency-bound, not HBM-bound: algorithmic HBM traffic is 4F B/px in + 8 B/px out.
+#include <algorithm>
 #include <cmath>
+#include <queue>
 
 #include "common.h"
 
-struct __align__(16) rf_node {
+struct __align__(8) rf_node {
     float thr;
-    int feature;
-    int left;
-    unsigned right;  // bit 31: missing_go_to_left
+    unsigned bits;
 };
+#define RF_LEAF 0x80000000u
+#define RF_MISS 0x40000000u
+#define RF_PURE 0x20000000u  // leaf only: value row is one-hot, class in bits 24-28
 
-#define RF_THREADS 256
+#define RF_THREADS_MAX 1024
 #define RF_NCMAX 8
 
 struct rf_planes {
     const float *p[RSSEG_MAX_FEATURES];
 };
 
-template <int NC>
+struct rf_tree {
+    int node_off;  // first node of the tree in the node array
+    int n_nodes;
+    int leaf_off;  // first row of the tree in the leaf-value table
+    int pad;
+};
+
+template <int NC, int RF_THREADS>
 __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
-                                                         const int *__restrict__ tree_off, int n_trees,
+                                                         const rf_tree *__restrict__ trees, int n_trees, int ntop,
                                                          const double *__restrict__ leafval, int n_classes,
                                                          const long long *__restrict__ classes, long long *__restrict__ out)
 {
-    extern __shared__ float feat[];  // [F][RF_THREADS]
+    extern __shared__ __align__(16) char smem[];
+    float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_THREADS]
+    rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_THREADS);       // [2][ntop]
     const int64_t i = (int64_t)blockIdx.x * RF_THREADS + threadIdx.x;
     for (int f = 0; f < F; f++) feat[f * RF_THREADS + threadIdx.x] = i < n ? pl.p[f][i] : 0.f;
-    // each lane reads back only what it wrote: no barrier needed
-    if (i >= n) return;
+    // tree 0's top block
+    {
+        const rf_tree t0 = trees[0];
+        const int cnt = t0.n_nodes < ntop ? t0.n_nodes : ntop;
+        for (int j = threadIdx.x; j < cnt; j += RF_THREADS) top[j] = nodes[t0.node_off + j];
+    }
+    __syncthreads();
     double acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) acc[c] = 0.0;
     for (int t = 0; t < n_trees; t++) {
-        const rf_node *tn = nodes + tree_off[t];
-        rf_node nd = tn[0];
-        while (nd.feature >= 0) {
-            const float x = feat[nd.feature * RF_THREADS + threadIdx.x];
-            const int right = (int)(nd.right & 0x7fffffffu);
-            int next;
-            if (x != x) next = (nd.right >> 31) ? nd.left : right;
-            else next = x <= nd.thr ? nd.left : right;
-            nd = tn[next];
-        }
-        const double *v = leafval + (size_t)nd.left * n_classes;
+        const rf_tree tr = trees[t];
+        const rf_node *buf = top + (size_t)(t & 1) * ntop;
+        // issue the copy of the next tree's top block (held in registers during the walk)
+        constexpr int NPRE = 8192 / RF_THREADS;  // ntop <= 8192
+        rf_node pre[NPRE];
+        int pcnt = 0, poff = 0;
+        if (t + 1 < n_trees) {
+            const rf_tree tn = trees[t + 1];
+            pcnt = tn.n_nodes < ntop ? tn.n_nodes : ntop;
+            poff = tn.node_off;
 #pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (c < n_classes) acc[c] += v[c];
+            for (int r = 0; r < NPRE; r++) {
+                const int j = threadIdx.x + r * RF_THREADS;
+                if (j < pcnt) pre[r] = nodes[poff + j];
+            }
+        }
+        if (i < n) {
+            const rf_node *tn = nodes + tr.node_off;
+            const int lim = tr.n_nodes < ntop ? tr.n_nodes : ntop;
+            rf_node nd = buf[0];
+            while (!(nd.bits & RF_LEAF)) {
+                const float x = feat[((nd.bits >> 24) & 63u) * RF_THREADS + threadIdx.x];
+                const unsigned left = nd.bits & 0xffffffu;
+                bool go_left;
+                if (x != x) go_left = (nd.bits & RF_MISS) != 0;
+                else go_left = x <= nd.thr;
+                const unsigned next = go_left ? left : left + 1u;
+                nd = (int)next < lim ? buf[next] : tn[next];
+            }
+            if (nd.bits & RF_PURE) {
+                const int cls = (nd.bits >> 24) & 31u;
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc[c] += (c == cls) ? 1.0 : 0.0;
+            } else {
+                const double *v = leafval + (size_t)(tr.leaf_off + (int)(nd.bits & 0xffffffu)) * n_classes;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    if (c < n_classes) acc[c] += v[c];
+            }
+        }
+        if (t + 1 < n_trees) {
+            rf_node *nb = top + (size_t)((t + 1) & 1) * ntop;
+#pragma unroll
+            for (int r = 0; r < NPRE; r++) {
+                const int j = threadIdx.x + r * RF_THREADS;
+                if (j < pcnt) nb[j] = pre[r];
+            }
+        }
+        __syncthreads();
     }
+    if (i >= n) return;
     int best = 0;
     double bv = acc[0] / (double)n_trees;
 #pragma unroll
@@ -87,44 +143,76 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     if (nn < n_trees || nn > 0x7ffffff0) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: bad node count %lld", (long long)nn);
     std::vector<rf_node> nodes((size_t)nn);
     std::vector<double> leaf;
-    std::vector<int> toff(n_trees + 1);
-    for (int t = 0; t <= n_trees; t++) toff[t] = (int)tree_off[t];
+    std::vector<rf_tree> trees(n_trees);
+    std::vector<int> order, newid;
     for (int t = 0; t < n_trees; t++) {
         const int64_t b = tree_off[t], e = tree_off[t + 1];
-        for (int64_t g = b; g < e; g++) {
-            rf_node &nd = nodes[(size_t)g];
+        const int cnt = (int)(e - b);
+        if (cnt < 1 || cnt > 0xffffff) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "forest_load: tree %d has %d nodes (max 16777215)", t, cnt);
+        // breadth-first order; children of a node end up adjacent
+        order.clear();
+        newid.assign(cnt, -1);
+        order.push_back(0);
+        newid[0] = 0;
+        for (size_t h = 0; h < order.size(); h++) {
+            const int g = order[h];
+            if (left[b + g] == -1) continue;
+            const int l = left[b + g], r = right[b + g];
+            if (l < 0 || r < 0 || l >= cnt || r >= cnt || newid[l] != -1 || newid[r] != -1 || feature[b + g] < 0 || feature[b + g] >= n_features)
+                return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: node %d of tree %d is malformed", g, t);
+            newid[l] = (int)order.size();
+            order.push_back(l);
+            newid[r] = (int)order.size();
+            order.push_back(r);
+        }
+        if ((int)order.size() != cnt) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: tree %d has unreachable nodes", t);
+        trees[t].node_off = (int)b;
+        trees[t].n_nodes = cnt;
+        trees[t].leaf_off = (int)(leaf.size() / n_classes);
+        trees[t].pad = 0;
+        int nleaf = 0;
+        for (int h = 0; h < cnt; h++) {
+            const int64_t g = b + order[h];
+            rf_node &nd = nodes[(size_t)(b + h)];
             if (left[g] == -1) {
                 nd.thr = 0.f;
-                nd.feature = -1;
-                nd.left = (int)(leaf.size() / n_classes);
-                nd.right = 0;
-                for (int c = 0; c < n_classes; c++) leaf.push_back(value[(size_t)g * n_classes + c]);
+                const double *v = value + (size_t)g * n_classes;
+                int ones = 0, zeros = 0, cls = 0;
+                for (int c = 0; c < n_classes; c++) {
+                    if (v[c] == 1.0) { ones++; cls = c; }
+                    else if (v[c] == 0.0) zeros++;
+                }
+                if (ones == 1 && zeros == n_classes - 1) {
+                    nd.bits = RF_LEAF | RF_PURE | ((unsigned)cls << 24);
+                } else {
+                    nd.bits = RF_LEAF | (unsigned)nleaf;
+                    nleaf++;
+                    for (int c = 0; c < n_classes; c++) leaf.push_back(v[c]);
+                }
             } else {
-                if (left[g] < 0 || right[g] < 0 || b + left[g] >= e || b + right[g] >= e || feature[g] < 0 || feature[g] >= n_features)
-                    return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: node %lld of tree %d is malformed", (long long)(g - b), t);
                 float f = (float)threshold[g];
                 if ((double)f > threshold[g]) f = nextafterf(f, -INFINITY);  // round toward -inf
                 nd.thr = f;
-                nd.feature = feature[g];
-                nd.left = left[g];
-                nd.right = (unsigned)right[g] | ((missing_go_left && missing_go_left[g]) ? 0x80000000u : 0u);
+                nd.bits = (unsigned)newid[left[g]] | ((unsigned)feature[g] << 24) | ((missing_go_left && missing_go_left[g]) ? RF_MISS : 0u);
+                if (newid[right[g]] != newid[left[g]] + 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: internal layout error");
             }
         }
     }
+    if (leaf.empty()) leaf.push_back(0.0);
     forest_dev &fd = ctx->forest;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (fd.d_nodes) HIPCHK(ctx, hipFree(fd.d_nodes));
     if (fd.d_leafval) HIPCHK(ctx, hipFree(fd.d_leafval));
     if (fd.d_treeoff) HIPCHK(ctx, hipFree(fd.d_treeoff));
     fd.d_nodes = fd.d_leafval = fd.d_treeoff = nullptr;
-    HIPCHK(ctx, hipMalloc(&fd.d_nodes, nodes.size() * sizeof(rf_node)));
+    HIPCHK(ctx, hipMalloc(&fd.d_nodes, nodes.size() * sizeof(rf_node) + 64));
     HIPCHK(ctx, hipMalloc(&fd.d_leafval, leaf.size() * sizeof(double) + 64));
-    HIPCHK(ctx, hipMalloc(&fd.d_treeoff, (toff.size() + n_classes * 2 + 2) * sizeof(long long)));
+    HIPCHK(ctx, hipMalloc(&fd.d_treeoff, n_classes * sizeof(long long) + trees.size() * sizeof(rf_tree) + 64));
     HIPCHK(ctx, hipMemcpy(fd.d_nodes, nodes.data(), nodes.size() * sizeof(rf_node), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(fd.d_leafval, leaf.data(), leaf.size() * sizeof(double), hipMemcpyHostToDevice));
-    // classes (int64) first, then the int32 tree offsets
+    // classes (int64) first, then the per-tree records
     HIPCHK(ctx, hipMemcpy(fd.d_treeoff, classes, n_classes * sizeof(long long), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy((char *)fd.d_treeoff + n_classes * sizeof(long long), toff.data(), toff.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy((char *)fd.d_treeoff + n_classes * sizeof(long long), trees.data(), trees.size() * sizeof(rf_tree), hipMemcpyHostToDevice));
     fd.n_trees = n_trees;
     fd.n_classes = n_classes;
     fd.n_features = n_features;
@@ -150,18 +238,27 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     }
     if (n == 0) return RSSEG_OK;
     const long long *d_classes = (const long long *)fd.d_treeoff;
-    const int *d_toff = (const int *)((const char *)fd.d_treeoff + fd.n_classes * sizeof(long long));
-    const size_t lds = sizeof(float) * (size_t)F * RF_THREADS;
-    const unsigned grid = (unsigned)ceil_div64(n, RF_THREADS);
-    {
+    const rf_tree *d_trees = (const rf_tree *)((const char *)fd.d_treeoff + fd.n_classes * sizeof(long long));
+    // workgroup size: 1024 pixels (16 waves hide the gathers below the LDS-resident top block) unless the
+    // environment asks for 512 (experiments); LDS = features TH * F * 4 B + two top blocks of ntop 8-byte nodes
+    int TH = 1024;
+    if (const char *e = getenv("RSSEG_FOREST_THREADS")) TH = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : 1024);
+    int ntop = 8192;
+    while (ntop > 256 && (size_t)F * TH * 4 + 2 * (size_t)ntop * sizeof(rf_node) > 150 * 1024) ntop >>= 1;
+    if (const char *e = getenv("RSSEG_FOREST_NTOP")) ntop = std::min(ntop, std::max(256, atoi(e)));
+    const size_t lds = (size_t)F * TH * 4 + 2 * (size_t)ntop * sizeof(rf_node);
+    const unsigned grid = (unsigned)ceil_div64(n, TH);
+    auto launch = [&](auto kern) -> int {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_scope ps(ctx, "forest");
-        if (fd.n_classes <= 4)
-            hipLaunchKernelGGL(k11_forest<4>, dim3(grid), dim3(RF_THREADS), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_toff,
-                               fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
-        else
-            hipLaunchKernelGGL(k11_forest<RF_NCMAX>, dim3(grid), dim3(RF_THREADS), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes,
-                               d_toff, fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
-    }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TH), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees, fd.n_trees, ntop,
+                           (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
+        return RSSEG_OK;
+    };
+    int rc;
+    if (fd.n_classes <= 4) rc = TH == 1024 ? launch(k11_forest<4, 1024>) : (TH == 512 ? launch(k11_forest<4, 512>) : launch(k11_forest<4, 256>));
+    else rc = TH == 1024 ? launch(k11_forest<RF_NCMAX, 1024>) : (TH == 512 ? launch(k11_forest<RF_NCMAX, 512>) : launch(k11_forest<RF_NCMAX, 256>));
+    if (rc != RSSEG_OK) return rc;
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
 }
