@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--size", type=int, default=0, help="tile edge (default 16384 for c3, 4096 for c2)")
     ap.add_argument("--glcm-step", type=int, default=1)
     ap.add_argument("--cpu-crop", type=int, default=2048)
@@ -125,16 +125,22 @@ def main():
     from rsseg.runtime import Context
     ctx = Context(local)
 
-    H = W = args.size or (16384 if args.config == "c3" else 4096)
+    H = W = args.size or (4096 if args.config == "c2" else 16384)
     k = 8 if args.config == "c3" else 6
-    F = 15 if args.config == "c3" else 7
+    F = {"c2": 7, "c3": 15, "c5": 19}[args.config]
     n_global = H * W * world
     bands = synth_tile(torch, device, H, W, rank * H)
     torch.cuda.synchronize()
 
+    forest_model = None
+    if args.config == "c5":
+        forest_model = fit_c5_forest(ctx, P, bands, H, W, n_global)
+
     def step():
         if args.config == "c3":
             return run_c3(ctx, P, bands, H, W, k, args.glcm_step, n_global)
+        if args.config == "c5":
+            return run_c5(ctx, P, bands, H, W, n_global)
         return run_c2(ctx, P, bands, k, n_global)
 
     def barrier():
@@ -158,7 +164,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fams = {}
-    for fam in ("glcm", "lloyd", "kpp", "select", "indices", "gram", "project", "resize"):
+    for fam in ("glcm", "lloyd", "kpp", "select", "indices", "gram", "project", "resize", "forest", "box", "stencil"):
         ms, cnt = ctx.prof_get(fam)
         if cnt:
             fams[fam] = (ms, cnt)
@@ -183,7 +189,10 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_np as O
-            v, desc = cpu_baseline(O, bands, H, W, args.cpu_crop, args.config, k)
+            if args.config == "c5":
+                v, desc = cpu_baseline_c5(O, forest_model, bands, H, W, min(args.cpu_crop, 1024))
+            else:
+                v, desc = cpu_baseline(O, bands, H, W, args.cpu_crop, args.config, k)
             cpu = {"value": round(v, 4), "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": desc}
         out = {
             "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
@@ -191,14 +200,64 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{H}x{W}x7 synthetic TM tile per GPU, robust-normalise + 7 spectral indices"
                                     + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if args.config == "c3" else "")
-                                    + f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)"),
-                       "tile": [H, W, 7], "n_features": F, "n_clusters": k, "kmeans_n_iter": int(meta["n_iter"]),
+                                    + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if args.config != "c5" else
+                                       " + PCA + GLCM(21/21) + 7x7 context + morphology/std/Sobel -> 19-feature stack -> RandomForest(100 trees, max_depth 16) inference")),
+                       "tile": [H, W, 7], "n_features": F, "n_clusters": k if args.config != "c5" else None,
+                       "kmeans_n_iter": int(meta["n_iter"]) if meta else None,
                        "parallelism": f"tile-sharded x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _label_field(H, W, row0=0):
+    y = (np.arange(H) + row0)[:, None]
+    x = np.arange(W)[None, :]
+    return ((y // 64) * 7 + (x // 64) * 3) % 8
+
+
+def fit_c5_forest(ctx, P, bands, H, W, n_global):
+    """BASELINE config 5: RandomForestClassifier(100, max_depth=16, random_state=42) fitted on the host on
+    200 000 pixels of the 19-feature stack with the prototype index as label and 10 % label noise, so that
+    depth 16 is reached; same object schema as the reference's rf_samples_model.pkl.  Training is outside
+    the timed region (out of scope)."""
+    import torch
+    from sklearn.ensemble import RandomForestClassifier
+    from rsseg.forest import flatten_forest
+    planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
+    fp = P.stack19_forest_planes(ctx, planes)
+    rng = np.random.default_rng(355)
+    idx = rng.choice(H * W, 200000, replace=False)
+    ti = torch.from_numpy(idx).to(fp[0].device)
+    X = np.stack([p[ti].cpu().numpy() for p in fp], 1)
+    y = _label_field(H, W).reshape(-1)[idx].astype(np.int64)
+    flip = rng.random(idx.size) < 0.1
+    y[flip] = rng.integers(0, 8, int(flip.sum()))
+    model = RandomForestClassifier(n_estimators=100, max_depth=16, random_state=42, n_jobs=-1).fit(X, y)
+    ctx.forest_load(flatten_forest(model))
+    return model
+
+
+def run_c5(ctx, P, bands, H, W, n_global):
+    planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
+    labels = ctx.forest_predict(P.stack19_forest_planes(ctx, planes))
+    return labels, None
+
+
+def cpu_baseline_c5(O, model, tile_bands, H, W, crop):
+    """Oracle feature stack + the same sklearn forest (n_jobs=None, as the reference calls it) on a crop."""
+    from threadpoolctl import threadpool_limits
+    c = min(crop, H, W)
+    b = [t.reshape(H, W)[:c, :c].cpu().numpy().copy() for t in tile_bands]
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=1):
+        _, hier = O.run_feature_extraction_stage(b)
+        model.n_jobs = None
+        model.predict(hier["all"].reshape(-1, 19))
+    dt = time.perf_counter() - t0
+    return (c * c / 1e6) / dt, f"{c}x{c}x7 crop, oracle 19-feature stack + sklearn forest.predict (n_jobs=None), 1 thread, {dt:.1f} s"
 
 
 def run_c2(ctx, P, bands, k, n_global):

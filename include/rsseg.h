@@ -123,6 +123,9 @@ int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int levels, 
                   float *const *d_props);
 /* float32 plane in [0,1] -> uint8 by truncation of x*mult (indices.py:268, 415, 458). */
 int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, uint8_t *d_q);
+/* uint8 plane -> float32 of (uint8 / 255.0 in float64): the value sklearn sees for the morphological members
+ * (features[...] = gradient / 255.0, indices.py:436-440; float32 cast sklearn/ensemble/_forest.py:640). */
+int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out);
 /* cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) for float32 (indices.py:308). */
 int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw);
 

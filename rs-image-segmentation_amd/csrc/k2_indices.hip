@@ -132,6 +132,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_quantize(const float *__restric
     if (t < n) q[t] = (uint8_t)(int)(x[t] * mult);
 }
 
+__global__ __launch_bounds__(K2_THREADS) void k2_u8_unit(const uint8_t *__restrict__ q, float *__restrict__ y, int64_t n)
+{
+    // uint8 / 255.0 evaluated in float64 (indices.py:436-440), then the float32 cast sklearn applies to X
+    for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K2_THREADS)
+        y[i] = (float)((double)q[i] / 255.0);
+}
+
 static int stream_grid(int64_t n4)
 {
     return (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n4, K2_THREADS)));
@@ -199,6 +206,19 @@ extern "C" int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, fl
     {
         prof_scope ps(ctx, "indices");
         hipLaunchKernelGGL(k2_quantize, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_q || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "u8_to_unit: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "indices");
+        hipLaunchKernelGGL(k2_u8_unit, dim3(stream_grid(n)), dim3(K2_THREADS), 0, ctx->stream, d_q, d_out, n);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

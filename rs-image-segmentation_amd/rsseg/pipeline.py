@@ -110,17 +110,23 @@ def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size
     return {k: ctx.resize_bilinear(v, oh, ow, H, W) for k, v in zip(GLCM_NAMES, small)}, (oh, ow)
 
 
-def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=21, glcm_step=21, glcm_levels=32):
+def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=21, glcm_step=21, glcm_levels=32,
+                    n_global: Optional[int] = None):
     """The 19 planes of hierarchical_features['all'] (scripts/2:112-127), in stack order.
     Returns (planes, dtypes_note): all planes float32 except index 16 (gradient_5) which is uint8 on
     the device and becomes uint8/255.0 (float64) on the host, as in indices.py:440."""
-    lohi = band_lohi(ctx, bands)
+    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
-    pcs, ratio, model = pca(ctx, norm_all, None, True)
+    fused = all(q["center"] is not None for q in qb)
+    pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
     level1 = [idx["ndwi"], idx["mndwi"], idx["ndvi"], idx["evi"], idx["ndbi"], idx["bsi"], pcs[0]]
     ctx_planes = [ctx.box_mean(p, H, W, 7, L.BORDER_REFLECT) for p in level1]
-    nir2 = renormalize(ctx, norm_all[3])
+    if fused:
+        nir2 = ctx.normalize(norm_all[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]))
+    else:
+        nir2 = renormalize(ctx, norm_all[3], n_global)
     glcm, _ = glcm_features(ctx, nir2, H, W, glcm_levels, glcm_window, glcm_step)
     q255 = ctx.quantize_u8(nir2, 255.0)
     grad = ctx.morph_gradient(q255, H, W, 5)
@@ -129,6 +135,13 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
     planes = level1 + ctx_planes + [glcm["contrast"], glcm["homogeneity"], grad, std5, sob]
     extras = dict(indices=idx, norm=norm_all, pca=pcs, pca_ratio=ratio, pca_model=model, glcm=glcm, lohi=lohi)
     return planes, extras
+
+
+def stack19_forest_planes(ctx: Context, planes: Sequence) -> List:
+    """The float32 matrix RandomForestClassifier.predict sees for the 19-feature stack: float32 planes as
+    they are, the uint8 morphological gradient as float32(uint8 / 255.0)."""
+    import torch
+    return [ctx.u8_to_unit(p) if p.dtype == torch.uint8 else p for p in planes]
 
 
 def stack19_to_host(planes: Sequence, H: int, W: int) -> np.ndarray:

@@ -168,6 +168,12 @@ class Context:
                                              C.c_void_p(q.data_ptr())))
         return q
 
+    def u8_to_unit(self, q):
+        torch = _torch()
+        out = self.empty(q.numel(), torch.float32)
+        self._chk(self.lib.rsseg_u8_to_unit_f32(self.h, C.c_void_p(q.data_ptr()), q.numel(), C.c_void_p(out.data_ptr())))
+        return out
+
     # ---- K3 ------------------------------------------------------------------------------------
     def pca_fit_transform(self, bands: Sequence, center: Optional[np.ndarray], scale: Optional[np.ndarray],
                           n_components: int):

@@ -251,10 +251,9 @@ def test_stack19_and_class_map_end_to_end(ctx, scene, oracle, golden_dir):
         assert np.array_equal(stack[:, :, c], hier["all"][:, :, c]), c
     f = dict(np.load(os.path.join(golden_dir, "rf_samples_model_flat.npz")))
     ctx.forest_load(f)
-    import torch
-    fplanes = [p.to(torch.float32) / 255.0 if p.dtype == torch.uint8 else p for p in planes]
+    fplanes = P.stack19_forest_planes(ctx, planes)
     # gradient_5 is float64 uint8/255.0 in the reference and is cast to float32 by sklearn
-    fplanes[16] = dev(ctx, (host(planes[16]).astype(np.float64) / 255.0).astype(np.float32))
+    assert np.array_equal(host(fplanes[16]), (host(planes[16]).astype(np.float64) / 255.0).astype(np.float32))
     cm = host(ctx.forest_predict(fplanes), (600, 600))
     assert cm.dtype == np.int64
     assert float(np.mean(cm == scene["class_map"])) >= 0.999
