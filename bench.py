@@ -153,6 +153,9 @@ def main():
         labels, meta = step()
     ctx.prof_enable(True)
     ctx.prof_reset()
+    if getattr(ctx, "_aux", None) is not None:
+        ctx._aux.prof_enable(True)
+        ctx._aux.prof_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,6 +169,9 @@ def main():
     fams = {}
     for fam in ("glcm", "lloyd", "kpp", "select", "indices", "gram", "project", "resize", "forest", "box", "stencil"):
         ms, cnt = ctx.prof_get(fam)
+        if getattr(ctx, "_aux", None) is not None:  # kernels issued on the second stream
+            ms2, cnt2 = ctx._aux.prof_get(fam)
+            ms, cnt = ms + ms2, cnt + cnt2
         if cnt:
             fams[fam] = (ms, cnt)
     ctx.prof_enable(False)
@@ -268,7 +274,7 @@ def run_c2(ctx, P, bands, k, n_global):
 
 
 def run_c3(ctx, P, bands, H, W, k, glcm_step, n_global):
-    labels, meta, _ = P.config3(ctx, bands, H, W, k, 7, glcm_step, 3, n_global)
+    labels, meta, _ = P.config3(ctx, bands, H, W, k, 7, glcm_step, 3, n_global, overlap=os.environ.get("RSSEG_OVERLAP", "0") == "1")
     return labels, meta
 
 

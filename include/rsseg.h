@@ -65,6 +65,11 @@ int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out);
 void rsseg_ctx_destroy(rsseg_ctx *ctx);
 const char *rsseg_last_error(const rsseg_ctx *ctx);
 const char *rsseg_version(void);
+/* Asynchronous mode: entry points whose results stay on the device (normalize, indices, quantize, glcm, resize,
+ * window operators, forest_predict) return right after enqueueing on the context's stream; rsseg_ctx_sync waits.
+ * Used to run the VALU-bound GLCM on a second stream beside the HBM-bound passes (rsseg/pipeline.py). */
+int rsseg_ctx_set_async(rsseg_ctx *ctx, int on);
+int rsseg_ctx_sync(rsseg_ctx *ctx);
 /* d_comm: device buffer of comm_bytes (>= 1 MiB) owned by the caller, visible to the hook. */
 int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn fn, void *user,
                        void *d_comm, size_t comm_bytes);

@@ -32,6 +32,7 @@ struct rsseg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool async_mode = false;  // entry points return after enqueueing (no trailing stream sync)
     char err[512] = {0};
     // communication
     int rank = 0, world = 1;

@@ -122,6 +122,22 @@ int pin_reserve(rsseg_ctx *ctx, size_t bytes)
 
 int stream_sync(rsseg_ctx *ctx)
 {
+    if (ctx->async_mode) return RSSEG_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_ctx_set_async(rsseg_ctx *ctx, int on)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    ctx->async_mode = on != 0;
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_ctx_sync(rsseg_ctx *ctx)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RSSEG_OK;
 }

@@ -46,6 +46,8 @@ SIGNATURES = {
     "rsseg_last_error": (C.c_char_p, [_vp]),
     "rsseg_version": (C.c_char_p, []),
     "rsseg_ctx_set_comm": (_int, [_vp, _int, _int, ALLREDUCE_FN, _vp, _vp, C.c_size_t]),
+    "rsseg_ctx_set_async": (_int, [_vp, _int]),
+    "rsseg_ctx_sync": (_int, [_vp]),
     "rsseg_prof_enable": (_int, [_vp, _int]),
     "rsseg_prof_reset": (_int, [_vp]),
     "rsseg_prof_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -163,23 +163,35 @@ def config2(ctx: Context, bands: Sequence, k: int = 6):
 
 
 def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3,
-            n_global: Optional[int] = None):
+            n_global: Optional[int] = None, overlap: bool = False):
     """BASELINE config 3: 7 indices + 5 GLCM properties (window 7, 4 angles) + PCA(3) -> 15 float32
-    features -> KMeans(k).  One select per band serves all percentile requests (band_quantile_bundle)."""
-    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    features -> KMeans(k).  One select per band serves all percentile requests (band_quantile_bundle).
+    overlap=True enqueues the GLCM chain (quantise -> windows -> 5 bilinear upsamples) on a second HIP
+    stream beside the selects / indices / PCA of the other bands and joins before KMeans.  Measured on MI355X
+    (profiles/r01_overlap_note.md): the GLCM kernel fills every CU and slows down by what the other stream
+    executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default."""
+    NIR = 3
+    qn = band_quantile_bundle(ctx, bands[NIR], n_global)
+    fused = qn["center"] is not None
+    nir_norm = ctx.normalize(bands[NIR], float(qn["lo"]), float(qn["hi"]))
+    if fused:
+        lo2, hi2 = qn["lo2"], qn["hi2"]
+    else:
+        lo2, hi2 = band_percentiles(ctx, nir_norm, (2, 98), n_global)
+    nir2 = ctx.normalize(nir_norm, float(lo2), float(hi2))
+    g = ctx.aux() if overlap else ctx
+    if overlap:
+        g.torch_stream.wait_stream(ctx.torch_stream)
+    glcm, _ = glcm_features(g, nir2, H, W, 32, glcm_window, glcm_step)   # asynchronous on the aux stream
+    qb = [qn if i == NIR else band_quantile_bundle(ctx, b, n_global) for i, b in enumerate(bands)]
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
-    if all(q["center"] is not None for q in qb):
-        stats = [(q["center"], q["scale"]) for q in qb]
-        lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
-    else:
-        stats = None
-        lo2, hi2 = band_percentiles(ctx, norm_all[3], (2, 98), n_global)
+    stats = [(q["center"], q["scale"]) for q in qb] if all(q["center"] is not None for q in qb) else None
     pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, stats)
-    nir2 = ctx.normalize(norm_all[3], float(lo2), float(hi2))
     del norm_all, norms
-    glcm, _ = glcm_features(ctx, nir2, H, W, 32, glcm_window, glcm_step)
+    if overlap:
+        g.sync()
     planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes

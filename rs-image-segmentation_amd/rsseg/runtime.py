@@ -52,7 +52,8 @@ class Context:
     """Owns an rsseg_ctx.  `group` (optional) is a torch.distributed process group: when its world
     size is > 1 the library's reductions go through RCCL (or gloo in CPU tests of the hook)."""
 
-    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None):
+    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None, stream=None):
+        """stream: a torch.cuda.Stream for this context (default: torch's current stream)."""
         torch = _torch()
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -60,8 +61,8 @@ class Context:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.rsseg_ctx_create(device, C.c_void_p(stream), C.byref(h))
+        self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self.lib.rsseg_ctx_create(device, C.c_void_p(self.torch_stream.cuda_stream), C.byref(h))
         if rc != 0:
             raise RssegError(f"rsseg_ctx_create failed ({rc}): {self.lib.rsseg_last_error(None).decode()}")
         self.h = h
@@ -84,7 +85,32 @@ class Context:
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
 
+    def set_async(self, on: bool = True):
+        """Asynchronous entry points.  Buffers handed out by empty() are then kept alive until sync(): the
+        caching allocator would otherwise recycle a temporary the moment Python drops it, while kernels that
+        read it are still queued on this context's stream."""
+        self._chk(self.lib.rsseg_ctx_set_async(self.h, int(on)))
+        self._async = bool(on)
+        self._keep = []
+
+    def sync(self):
+        self._chk(self.lib.rsseg_ctx_sync(self.h))
+        self._keep = []
+
+    def aux(self):
+        """A second context on its own HIP stream (same device, asynchronous entry points): lets a
+        VALU-bound kernel run beside the HBM-bound passes issued through this context."""
+        if getattr(self, "_aux", None) is None:
+            torch = _torch()
+            a = Context(self.device.index, use_dist=False, stream=torch.cuda.Stream(self.device))
+            a.set_async(True)
+            self._aux = a
+        return self._aux
+
     def close(self):
+        if getattr(self, "_aux", None) is not None:
+            self._aux.close()
+            self._aux = None
         if getattr(self, "h", None):
             self.lib.rsseg_ctx_destroy(self.h)
             self.h = None
@@ -112,7 +138,10 @@ class Context:
 
     def empty(self, n, dtype):
         torch = _torch()
-        return torch.empty(int(n), dtype=dtype, device=self.device)
+        t = torch.empty(int(n), dtype=dtype, device=self.device)
+        if getattr(self, "_async", False):
+            self._keep.append(t)
+        return t
 
     @staticmethod
     def _pp(tensors: Sequence) -> "C.Array":
