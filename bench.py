@@ -8,8 +8,9 @@ One "step" = one pass of the hot path over the raster already resident in HBM:
       GLCM (7x7 window, step 1, 32 levels, 4 angles, 5 properties, bilinear back to H x W) ->
       15 float32 features -> MinMax + KMeans(k=8, k-means++, random_state=42) -> int32 label plane
   config c2 (BASELINE configs[1]): 7 indices -> KMeans(k=6) on a 4096 x 4096 raster.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank holds one H x W tile
-of an (N*H) x W scene (weak scaling); histograms, PCA sums and KMeans partials go through RCCL.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); ONE (N*H) x W scene is sharded by rows,
+every rank owns H rows (weak scaling) plus the few NIR halo rows its texture windows read; histograms, PCA
+sums and KMeans partials go through RCCL, and the label map equals the single-GPU result for that scene.
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,23 +28,32 @@ for p in (os.path.join(ROOT, "rs-image-segmentation_amd"), ROOT):
 import numpy as np  # noqa: E402
 
 
-def synth_tile(torch, device, H, W, row0, bands=7, stripe=2048):
+SYNTH_STRIPE = 2048
+
+
+def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
     """SURVEY.md §8(d) generator, evaluated on the device: 8 spectral prototypes on a 64-px checkerboard
     + N(0, 6) noise, clipped, truncated to uint8, stored as float32 (integer-valued DN like the real
-    preprocessed tile).  Deterministic in the global row position."""
+    preprocessed tile).  Returns the planes `want` for GLOBAL rows [g0, g1); every 2048-row stripe of the scene
+    has its own seed and is always generated whole, so any rank reproduces any row of the scene exactly
+    (needed for the texture halos of a row-sharded raster)."""
     proto = torch.tensor(np.random.default_rng(355).integers(20, 230, (8, bands)), dtype=torch.float32, device=device)
-    out = [torch.empty(H * W, dtype=torch.float32, device=device) for _ in range(bands)]
+    want = list(want)
+    out = {b: torch.empty((g1 - g0) * W, dtype=torch.float32, device=device) for b in want}
     x = torch.arange(W, device=device)[None, :]
-    for r0 in range(0, H, stripe):
-        rows = min(stripe, H - r0)
+    for s in range(g0 // SYNTH_STRIPE, (g1 - 1) // SYNTH_STRIPE + 1):
+        s0 = s * SYNTH_STRIPE
         g = torch.Generator(device=device)
-        g.manual_seed(355_000 + (row0 + r0) // stripe)
-        y = (torch.arange(rows, device=device) + (row0 + r0))[:, None]
+        g.manual_seed(355_000 + s)
+        y = (torch.arange(SYNTH_STRIPE, device=device) + s0)[:, None]
         lab = ((y // 64) * 7 + (x // 64) * 3) % 8
+        a, b_ = max(g0, s0), min(g1, s0 + SYNTH_STRIPE)
         for b in range(bands):
-            v = proto[lab, b] + torch.randn(rows, W, generator=g, device=device) * 6.0
-            out[b][r0 * W:(r0 + rows) * W] = v.clamp_(0, 255).to(torch.uint8).to(torch.float32).reshape(-1)
-    return out
+            noise = torch.randn(SYNTH_STRIPE, W, generator=g, device=device)  # always drawn: keeps the stream aligned
+            if b in out:
+                v = (proto[lab, b] + noise * 6.0)[a - s0:b_ - s0]
+                out[b][(a - g0) * W:(b_ - g0) * W] = v.clamp_(0, 255).to(torch.uint8).to(torch.float32).reshape(-1)
+    return [out[b] for b in want]
 
 
 # algorithmic HBM bytes per pixel and launch of each kernel family (SURVEY.md §8(d); DESIGN.md §5)
@@ -107,6 +117,8 @@ def main():
     ap.add_argument("--glcm-step", type=int, default=1)
     ap.add_argument("--cpu-crop", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -116,11 +128,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     from rsseg import pipeline as P
     from rsseg.runtime import Context
     ctx = Context(local)
@@ -129,7 +146,14 @@ def main():
     k = 8 if args.config == "c3" else 6
     F = {"c2": 7, "c3": 15, "c5": 19}[args.config]
     n_global = H * W * world
-    bands = synth_tile(torch, device, H, W, rank * H)
+    Hg, r0, r1 = H * world, rank * H, (rank + 1) * H       # one (world*H) x W scene, this rank owns rows [r0, r1)
+    bands = synth_rows(torch, device, W, r0, r1)
+    nir_ext, i0 = None, r0
+    if world > 1 and args.config == "c3":
+        _, _, i0, i1 = P.glcm_halo_rows(Hg, r0, r1, 7, args.glcm_step)
+        top = synth_rows(torch, device, W, i0, r0, want=[3])[0] if i0 < r0 else bands[3][:0]
+        bot = synth_rows(torch, device, W, r1, i1, want=[3])[0] if i1 > r1 else bands[3][:0]
+        nir_ext = torch.cat([top, bands[3], bot])
     torch.cuda.synchronize()
 
     forest_model = None
@@ -137,6 +161,9 @@ def main():
         forest_model = fit_c5_forest(ctx, P, bands, H, W, n_global)
 
     def step():
+        if args.config == "c3" and world > 1:
+            labels, meta, _ = P.config3_striped(ctx, bands, nir_ext, Hg, W, r0, r1, i0, k, 7, args.glcm_step, 3)
+            return labels, meta
         if args.config == "c3":
             return run_c3(ctx, P, bands, H, W, k, args.glcm_step, n_global)
         if args.config == "c5":
@@ -204,13 +231,13 @@ def main():
             "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{H}x{W}x7 synthetic TM tile per GPU, robust-normalise + 7 spectral indices"
+            "config": {"workload": (f"{H}x{W}x7 synthetic TM raster per GPU ({H * world}x{W} scene row-striped over {world} GPU(s)), robust-normalise + 7 spectral indices"
                                     + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if args.config == "c3" else "")
                                     + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if args.config != "c5" else
                                        " + PCA + GLCM(21/21) + 7x7 context + morphology/std/Sobel -> 19-feature stack -> RandomForest(100 trees, max_depth 16) inference")),
                        "tile": [H, W, 7], "n_features": F, "n_clusters": k if args.config != "c5" else None,
                        "kmeans_n_iter": int(meta["n_iter"]) if meta else None,
-                       "parallelism": f"tile-sharded x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials"},
+                       "parallelism": f"row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -133,6 +133,10 @@ int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, u
 int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out);
 /* cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) for float32 (indices.py:308). */
 int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw);
+/* Row-striped form for sharded rasters: d_src holds rows [src_row0, src_row0 + sh_local) of a source sh rows tall,
+ * d_dst receives rows [dst_row0, dst_row0 + dh_local) of the dh x dw result; identical values to the un-sharded call. */
+int rsseg_resize_bilinear_rows_f32(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw, int src_row0, int sh,
+                                   float *d_dst, int dh_local, int dw, int dst_row0, int dh);
 
 /* ---- K6/K7/K8: window operators ---------------------------------------------------------- */
 /* cv2.boxFilter(normalize=True) / cv2.blur for float32 (indices.py:770-771, 537, 541): k x k mean,

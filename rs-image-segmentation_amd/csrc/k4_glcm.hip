@@ -140,6 +140,18 @@ template <int R, int C> __device__ __forceinline__ int px_at(const unsigned (&w)
     return (int)((w[R][C >> 2] >> (8 * (C & 3))) & 0xffu);
 }
 
+__device__ __forceinline__ void pin32(unsigned &v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+__device__ __forceinline__ void pin_pair(unsigned &a, unsigned &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(a), "+v"(b));
+#endif
+}
 __device__ __forceinline__ void pin64(long long &v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -219,12 +231,16 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         unsigned da, db;
         const unsigned ka = pair_key(xa, ya, da), kb = pair_key(xb, yb, db);
         K[p] = ka | (kb << 16);
+        pin32(K[p]);  // materialise the packed key now: otherwise the 4 min/max values per pair stay live until a
+                      // later key-assembly phase (4P registers)
         HqA += hq[da];
         HqB += hq[db];
         // pin the two accumulation chains: left alone, the optimiser re-associates the 2P integer adds into
         // a tree, which keeps all 2P 64-bit LUT values alive at once (4P registers -> one wave per SIMD)
-        pin64(HqA);
-        pin64(HqB);
+        if constexpr (p % 6 == 5) {  // every 6 pairs: up to 12 LUT reads (24 registers) in flight, not 2P
+            pin64(HqA);
+            pin64(HqB);
+        }
     });
     __builtin_amdgcn_sched_barrier(0);  // phase boundaries keep the phases' live ranges from overlapping
     unsigned S1a, XYa, M2a, M1a, S1b, XYb, M2b, M1b;

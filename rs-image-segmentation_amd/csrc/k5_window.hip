@@ -135,11 +135,15 @@ __global__ __launch_bounds__(256) void k8_div(float *__restrict__ x, int64_t n, 
 }
 
 // cv2.resize INTER_LINEAR float32: horizontal taps (edge taps get weight 0), vertical taps clamp rows
+// Row-striped form: the local source holds rows [src_row0, src_row0 + sh_local) of a source sh rows tall and the
+// local destination rows [dst_row0, dst_row0 + dh_local) of a destination dh rows tall; taps are computed in
+// GLOBAL coordinates, so a stripe gets exactly the values of the un-sharded call.
 __global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, int sh, int sw, float *__restrict__ dst, int dh,
-                                                 int dw, double scale_x, double scale_y)
+                                                 int dw, double scale_x, double scale_y, int src_row0, int dst_row0, int dh_local)
 {
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= dw || py >= dh) return;
+    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), pyl = blockIdx.y * WG_Y + (threadIdx.x >> 6);
+    if (px >= dw || pyl >= dh_local) return;
+    const int py = pyl + dst_row0;
     float fx = (float)(((double)px + 0.5) * scale_x - 0.5);
     int sx = (int)floorf(fx);
     fx = fx - (float)sx;
@@ -153,11 +157,11 @@ __global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, 
     const int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
     const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
     const float b0 = 1.0f - fy, b1 = fy;
-    const float *r0 = src + (size_t)y0 * sw, *r1 = src + (size_t)y1 * sw;
+    const float *r0 = src + (size_t)(y0 - src_row0) * sw, *r1 = src + (size_t)(y1 - src_row0) * sw;
     const float t00 = r0[sx] * a0, t01 = r0[sx1] * a1, t10 = r1[sx] * a0, t11 = r1[sx1] * a1;
     const float h0 = t00 + t01, h1 = t10 + t11;
     const float u0 = h0 * b0, u1 = h1 * b1;
-    dst[(size_t)py * dw + px] = u0 + u1;
+    dst[(size_t)pyl * dw + px] = u0 + u1;
 }
 
 static dim3 grid2d(int H, int W) { return dim3((W + WG_X - 1) / WG_X, (H + WG_Y - 1) / WG_Y); }
@@ -248,16 +252,40 @@ extern "C" int rsseg_sobel_mag_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int
     return stream_sync(ctx);
 }
 
-extern "C" int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw)
+static int resize_rows(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw, int src_row0, int sh, float *d_dst, int dh_local,
+                       int dw, int dst_row0, int dh)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_src || !d_dst || sh < 1 || sw < 1 || dh < 1 || dw < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "resize: bad arguments");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!d_src || !d_dst || sh < 1 || sw < 1 || dh < 1 || dw < 1 || sh_local < 1 || dh_local < 1 || src_row0 < 0 || dst_row0 < 0 ||
+        src_row0 + sh_local > sh || dst_row0 + dh_local > dh)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "resize: bad arguments");
     const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
+    // the source stripe must hold every row the destination stripe taps
+    auto tap = [&](int py) {
+        float fy = (float)(((double)py + 0.5) * scale_y - 0.5);
+        return (int)floorf(fy);
+    };
+    const int need0 = std::min(std::max(tap(dst_row0), 0), sh - 1), need1 = std::min(std::max(tap(dst_row0 + dh_local - 1) + 1, 0), sh - 1);
+    if (need0 < src_row0 || need1 >= src_row0 + sh_local)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "resize: source stripe rows [%d,%d) do not cover the tapped rows [%d,%d]", src_row0,
+                       src_row0 + sh_local, need0, need1);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         prof_scope ps(ctx, "resize");
-        hipLaunchKernelGGL(k5_resize, grid2d(dh, dw), dim3(256), 0, ctx->stream, d_src, sh, sw, d_dst, dh, dw, scale_x, scale_y);
+        hipLaunchKernelGGL(k5_resize, grid2d(dh_local, dw), dim3(256), 0, ctx->stream, d_src, sh, sw, d_dst, dh, dw, scale_x, scale_y, src_row0,
+                           dst_row0, dh_local);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
+}
+
+extern "C" int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw)
+{
+    return resize_rows(ctx, d_src, sh, sw, 0, sh, d_dst, dh, dw, 0, dh);
+}
+
+extern "C" int rsseg_resize_bilinear_rows_f32(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw, int src_row0, int sh,
+                                              float *d_dst, int dh_local, int dw, int dst_row0, int dh)
+{
+    return resize_rows(ctx, d_src, sh_local, sw, src_row0, sh, d_dst, dh_local, dw, dst_row0, dh);
 }

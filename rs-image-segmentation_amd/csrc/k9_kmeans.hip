@@ -1089,12 +1089,31 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         }
         HIPCHK(ctx, hipGetLastError());
         RSCHK(pull_partials(L));
+        // potentials of all L candidates with ONE all-reduce: slot [l][rank] = this rank's chunk-sum total
+        u128 rt_all[KPP_MAXL][RSSEG_MAX_RANKS], tot_all[KPP_MAXL];
+        {
+            static long long lim[2 * KPP_MAXL * RSSEG_MAX_RANKS];
+            memset(lim, 0, sizeof(lim));
+            for (int l = 0; l < L; l++) {
+                u128 loc = 0;
+                if (n > 0)
+                    for (int64_t c2 = 0; c2 < nchunks; c2++) loc += h_part[(size_t)l * nchunks + c2];
+                lim[2 * (l * ctx->world + ctx->rank)] = (long long)(loc >> 32);
+                lim[2 * (l * ctx->world + ctx->rank) + 1] = (long long)(loc & 0xffffffffull);
+            }
+            RSCHK(comm_allreduce_host(ctx, lim, 2 * (int64_t)L * ctx->world, RSSEG_I64, RSSEG_SUM));
+            for (int l = 0; l < L; l++) {
+                tot_all[l] = 0;
+                for (int r = 0; r < ctx->world; r++) {
+                    rt_all[l][r] = ((u128)(unsigned long long)lim[2 * (l * ctx->world + r)] << 32) + (u128)(unsigned long long)lim[2 * (l * ctx->world + r) + 1];
+                    tot_all[l] += rt_all[l][r];
+                }
+            }
+        }
         int best = 0;
         T best_pot = (T)0;
         for (int l = 0; l < L; l++) {
-            u128 rt[RSSEG_MAX_RANKS], tot;
-            RSCHK(global_total(l, rt, &tot));
-            T pt = (T)((double)tot * (1.0 / 1099511627776.0));
+            T pt = (T)((double)tot_all[l] * (1.0 / 1099511627776.0));
             if (l == 0 || pt < best_pot) { best = l; best_pot = pt; }
         }
         current_pot = best_pot;
@@ -1102,7 +1121,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         init_idx[c] = cand_idx[best];
         // the best candidate's plane becomes the closest-distance plane; its chunk sums the prefix table
         if (n > 0) d_closest = cand_planes[best];
-        RSCHK(global_total(best, rank_tot, &total));
+        for (int r = 0; r < ctx->world; r++) rank_tot[r] = rt_all[best][r];
+        total = tot_all[best];
         for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[(size_t)best * nchunks + cc2];
     }
     if (info)

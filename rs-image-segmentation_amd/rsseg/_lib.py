@@ -61,6 +61,7 @@ SIGNATURES = {
     "rsseg_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, _vp]),
     "rsseg_u8_to_unit_f32": (_int, [_vp, _vp, _i64, _vp]),
     "rsseg_resize_bilinear_f32": (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
+    "rsseg_resize_bilinear_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _int, _int, _int]),
     "rsseg_box_mean_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "rsseg_local_std_f32": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "rsseg_morph_gradient_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),

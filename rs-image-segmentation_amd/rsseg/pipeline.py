@@ -195,3 +195,61 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes
+
+
+# ------------------------------------------------------------------------------------------------
+# one raster, row stripes over the ranks (BASELINE config 4)
+# ------------------------------------------------------------------------------------------------
+def stripe_rows(H: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [r0, r1) owned by `rank`: contiguous stripes in rank order."""
+    return (H * rank) // world, (H * (rank + 1)) // world
+
+
+def glcm_halo_rows(H: int, r0: int, r1: int, win: int, step: int) -> Tuple[int, int, int, int]:
+    """For output rows [r0, r1) of the bilinear upsample of the GLCM maps of an H-row raster: the small-map
+    rows [j0, j1] the stripe taps (cv2.resize pixel-centre mapping) and the image rows [i0, i1) those windows
+    read.  Returns (j0, j1, i0, i1)."""
+    sh = (H - win) // step + 1
+    scale = 1.0 / (H / sh)
+
+    def tap(y):
+        return int(np.floor(np.float32((y + 0.5) * scale - 0.5)))
+
+    j0 = min(max(tap(r0), 0), sh - 1)
+    j1 = min(max(tap(r1 - 1) + 1, 0), sh - 1)
+    return j0, j1, j0 * step, j1 * step + win
+
+
+def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: int, r1: int, i0: int, k: int = 8,
+                    glcm_window=7, glcm_step=1, n_pca=3):
+    """BASELINE config 3/4 on ONE H x W raster sharded by rows: this rank owns rows [r0, r1) (`bands`: its
+    stripe of each band) and additionally holds `nir_ext`, the NIR rows [i0, i0 + nir_ext.numel()/W) that its
+    texture windows read (glcm_halo_rows).  Percentiles, PCA and KMeans reduce over all ranks through the
+    context's all-reduce hook; the label stripe equals rows [r0, r1) of the single-GPU result bit for bit."""
+    n_global = H * W
+    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+    idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+    norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+    fused = all(q["center"] is not None for q in qb)
+    pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
+    if fused:
+        lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
+    else:
+        lo2, hi2 = band_percentiles(ctx, norm_all[3], (2, 98), n_global)
+    del norm_all, norms
+    ext_rows = nir_ext.numel() // W
+    nir_n = ctx.normalize(nir_ext, float(lohi[3, 0]), float(lohi[3, 1]))
+    nir2 = ctx.normalize(nir_n, float(lo2), float(hi2), out=nir_n)
+    q = ctx.quantize_u8(nir2, 31.0)
+    j0, j1, need_i0, need_i1 = glcm_halo_rows(H, r0, r1, glcm_window, glcm_step)
+    if need_i0 < i0 or need_i1 > i0 + ext_rows or (need_i0 - i0) % glcm_step:
+        raise ValueError(f"nir_ext rows [{i0},{i0 + ext_rows}) do not cover the texture rows [{need_i0},{need_i1})")
+    skip = need_i0 - i0
+    qv = q[skip * W:(skip + need_i1 - need_i0) * W]
+    small, (oh, ow) = ctx.glcm(qv, need_i1 - need_i0, W, 32, glcm_window, glcm_step)
+    sh = (H - glcm_window) // glcm_step + 1
+    glcm = [ctx.resize_bilinear_rows(m, oh, ow, j0, sh, r1 - r0, W, r0, H) for m in small]
+    planes = [idx[n] for n in INDEX_NAMES] + glcm + list(pcs)
+    labels, meta = ctx.kmeans_fit_predict(planes, k)
+    return labels, meta, planes

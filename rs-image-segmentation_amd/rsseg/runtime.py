@@ -237,6 +237,13 @@ class Context:
                                                      dh, dw))
         return dst
 
+    def resize_bilinear_rows(self, src, sh_local: int, sw: int, src_row0: int, sh: int, dh_local: int, dw: int, dst_row0: int, dh: int):
+        torch = _torch()
+        dst = self.empty(dh_local * dw, torch.float32)
+        self._chk(self.lib.rsseg_resize_bilinear_rows_f32(self.h, C.c_void_p(src.data_ptr()), sh_local, sw, src_row0, sh,
+                                                          C.c_void_p(dst.data_ptr()), dh_local, dw, dst_row0, dh))
+        return dst
+
     def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False):
         torch = _torch()
         out = self.empty(H * W, torch.float32)

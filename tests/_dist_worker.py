@@ -64,6 +64,21 @@ def main():
         np.savez(os.path.join(outdir, f"out_{rank}.npz"), labels=labels.cpu().numpy(), lohi=lohi, ratio=ratio,
                  pc0=pcs[0].cpu().numpy(), n_iter=meta["n_iter"], centers=meta["centers"], init=meta["init_indices"], r0=r0, r1=r1)
         ctx.close()
+    elif mode == "gpu_striped_c3":
+        from rsseg import pipeline as P
+        from rsseg.runtime import Context
+        data = np.load(os.path.join(outdir, "input.npz"))
+        bands = data["bands"]
+        H, W = bands.shape[1:]
+        r0, r1 = P.stripe_rows(H, world, rank)
+        j0, j1, i0, i1 = P.glcm_halo_rows(H, r0, r1, 7, 1)
+        ctx = Context(0, use_dist=True)
+        dev = [ctx.to_device(bands[i, r0:r1].reshape(-1)) for i in range(bands.shape[0])]
+        nir_ext = ctx.to_device(bands[3, i0:i1].reshape(-1))
+        labels, meta, planes = P.config3_striped(ctx, dev, nir_ext, H, W, r0, r1, i0, int(data["k"]))
+        np.savez(os.path.join(outdir, f"out_{rank}.npz"), labels=labels.cpu().numpy(), n_iter=meta["n_iter"], r0=r0, r1=r1,
+                 glcm0=planes[7].cpu().numpy(), glcm4=planes[11].cpu().numpy())
+        ctx.close()
     dist.destroy_process_group()
 
 

@@ -55,3 +55,30 @@ def test_sharded_equals_single_rank(ctx, oracle, golden_dir, tmp_path, world):
         assert np.array_equal(o["pc0"], pcs[0].cpu().numpy()[int(o["r0"]) * W:int(o["r1"]) * W])
         got.append(o["labels"])
     assert np.array_equal(np.concatenate(got), want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_striped_config3_equals_single_gpu(ctx, oracle, tmp_path, world):
+    """ONE raster sharded by rows, texture halos included: GLCM planes and labels of every stripe equal the rows
+    of the single-GPU config-3 result bit for bit."""
+    from rsseg import pipeline as P
+    H, W = 150, 128
+    bands = oracle.synthetic_raster(H, W)
+    k = 8
+    np.savez(tmp_path / "input.npz", bands=bands, k=k)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "gpu_striped_c3", str(r), str(world), port, str(tmp_path)])
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    labels, meta, planes = P.config3(ctx, [ctx.to_device(bands[i].reshape(-1)) for i in range(7)], H, W, k, 7, 1, 3)
+    want = labels.cpu().numpy()
+    g0, g4 = planes[7].cpu().numpy(), planes[11].cpu().numpy()
+    got = []
+    for r in range(world):
+        o = np.load(tmp_path / f"out_{r}.npz")
+        a, b = int(o["r0"]) * W, int(o["r1"]) * W
+        assert np.array_equal(o["glcm0"], g0[a:b]) and np.array_equal(o["glcm4"], g4[a:b])
+        assert int(o["n_iter"]) == meta["n_iter"]
+        got.append(o["labels"])
+    assert np.array_equal(np.concatenate(got), want)
