@@ -199,6 +199,24 @@ def main():
     report["class_map_agreement"] = float(np.mean(cm == class_map))
     report["class_map_samples_ok"] = int(sum(cm[y, x] == l for (x, y), l in zip(coords, labels)))
     report["class_map_samples_n"] = len(labels)
+    # ---------------- dict plumbing: key naming rule of normalize_features_structure --------
+    class _Affine:  # stands in for affine.Affine inside the reference module (isinstance check only)
+        pass
+    ref_ext.Affine = _Affine
+    z = np.zeros((4, 5), np.float32)
+    nested = {"hierarchical_features": {"level_1": np.zeros((4, 5, 3)), "all": np.zeros((4, 5, 6))},
+              "all_extracted_features_dict": {"NDVI": z, "pca_result": [z, z + 1], "glcm_features": {"contrast": z},
+                                              "variance_ratio": np.zeros(3), "scalar": 1.5},
+              "dimensions": (4, 5), "geo_transform": None, "crs": None}
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        nf = ref_ext.normalize_features_structure(nested)
+    nfs = {"keys": list(nf.keys()), "height": nf.get("height"), "width": nf.get("width"),
+           "shapes": {k: list(v.shape) for k, v in nf.items() if isinstance(v, np.ndarray)}}
+    with open(os.path.join(OUT, "nfs_golden.json"), "w") as f:
+        json.dump(nfs, f, indent=1)
+    report["nfs_keys"] = nfs["keys"]
+
     import sklearn
     report["versions"] = dict(numpy=np.__version__, sklearn=sklearn.__version__)
     with open(os.path.join(OUT, "PIN_REPORT.json"), "w") as f:

@@ -74,3 +74,30 @@ def run_kmeans_stage(hierarchical_all: np.ndarray, n_clusters: int = 7, ctx: Opt
     dev = [ctx.to_device(np.ascontiguousarray(hierarchical_all[:, :, i], dtype=dt).reshape(-1)) for i in range(c)]
     labels, _ = ctx.kmeans_fit_predict(dev, n_clusters)
     return (labels.cpu().numpy().reshape(h, w) + 1).astype(np.uint8)
+
+
+def run_classification_stage(features_filepath: str, method: str = "kmeans", output_dir: str = "output", n_clusters: int = 7,
+                             classifier=None, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
+    """KMeans / forest branches of run_classification_stage (scripts/3_classification.py:267-505) on a feature
+    file written by stage 2.  The shipped script filters the normalised dict with un-prefixed key names
+    (scripts/3:381-383) which never match stage 2's layout; this driver passes the key that
+    does exist, 'hierarchical_features_all'.  Writes <output_dir>/classification_<method>.npy (uint8, labels
+    starting at 1 for KMeans as in scripts/3:394) and returns the map; None when the stack is missing."""
+    from modules.features.extract import load_features, normalize_features_structure, unsupervised_kmeans_classification
+    feats = normalize_features_structure(load_features(features_filepath))
+    key = "hierarchical_features_all"
+    if key not in feats:
+        print(f"特征 '{key}' 不存在: {list(feats.keys())}")
+        return None
+    os.makedirs(output_dir, exist_ok=True)
+    if method == "kmeans":
+        out = (unsupervised_kmeans_classification(feats, n_clusters, [key]) + 1).astype(np.uint8)
+    elif method in ("rf", "supervised"):
+        if classifier is None:
+            raise ValueError("supervised classification needs a fitted classifier")
+        from modules.features.extract import supervised_classification_predict
+        out = supervised_classification_predict(feats[key], classifier)
+    else:
+        raise ValueError(f"unknown method {method!r} (rule-based classification is out of scope, SURVEY.md §2 row 11)")
+    np.save(os.path.join(output_dir, f"classification_{method}.npy"), out)
+    return out

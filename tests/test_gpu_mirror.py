@@ -95,3 +95,15 @@ def test_forest_entry_points(ctx, crop, golden_dir):
     assert bad.shape == (64, 64) and not bad.any()
     with pytest.raises(ValueError):
         E.supervised_classification_predict(X[0], f)
+
+
+def test_classification_stage_driver(ctx, crop, tmp_path):
+    """stage 2 files -> load_features -> normalize_features_structure -> KMeans on 'hierarchical_features_all'."""
+    from rsseg import stages
+    fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
+    paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
+    out = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls"), n_clusters=6)
+    assert out.shape == (96, 96) and out.dtype == np.uint8 and out.min() == 1 and out.max() == 6
+    assert np.array_equal(np.load(tmp_path / "cls" / "classification_kmeans.npy"), out)
+    direct = stages.run_kmeans_stage(hier["all"], 6)
+    assert np.array_equal(out, direct)

@@ -112,3 +112,32 @@ def test_context_without_gpu_fails_loudly():
     from rsseg.runtime import Context, RssegError
     with pytest.raises(RssegError):
         Context(0)
+
+
+def test_feature_dict_plumbing_matches_reference_key_rule(golden_dir, tmp_path):
+    """load_features / normalize_features_structure: same top-level keys, order and shapes as
+    the reference function produced for the same nested dict (tests/golden/nfs_golden.json)."""
+    import json
+    import pickle
+    from modules.features.extract import load_features, normalize_features_structure
+    z = np.zeros((4, 5), np.float32)
+    nested = {"hierarchical_features": {"level_1": np.zeros((4, 5, 3)), "all": np.zeros((4, 5, 6))},
+              "all_extracted_features_dict": {"NDVI": z, "pca_result": [z, z + 1], "glcm_features": {"contrast": z},
+                                              "variance_ratio": np.zeros(3), "scalar": 1.5},
+              "dimensions": (4, 5), "geo_transform": None, "crs": None}
+    want = json.load(open(os.path.join(golden_dir, "nfs_golden.json")))
+    p = str(tmp_path / "f.pkl")
+    pickle.dump(nested, open(p, "wb"))
+    got = normalize_features_structure(load_features(p))
+    assert list(got.keys()) == want["keys"]
+    assert got["height"] == want["height"] and got["width"] == want["width"]
+    assert {k: list(v.shape) for k, v in got.items() if isinstance(v, np.ndarray)} == want["shapes"]
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    np.save(str(tmp_path / "a.npy"), a)
+    d = normalize_features_structure(load_features(str(tmp_path / "a.npy")))
+    assert d["height"] == 3 and d["width"] == 4 and "all_features_feature_2" in d
+    with pytest.raises(FileNotFoundError):
+        load_features(str(tmp_path / "missing.pkl"))
+    with pytest.raises(ValueError):
+        open(str(tmp_path / "x.txt"), "w").write("x")
+        load_features(str(tmp_path / "x.txt"))
