@@ -217,26 +217,25 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
     long long HqA = 0, HqB = 0;
     static_for<P>([&](auto I) {
         constexpr int p = I;
-        int xa, ya, xb, yb;
-        if constexpr (G == 0) {
-            constexpr int ra_ = p / (WIN - 1), ca_ = p % (WIN - 1);  // (r,c)-(r,c+1)
-            constexpr int rb_ = p / WIN, cb_ = p % WIN;              // (r,c)-(r+1,c)
-            xa = px_at<ra_, ca_>(w); ya = px_at<ra_, ca_ + 1>(w);
-            xb = px_at<rb_, cb_>(w); yb = px_at<rb_ + 1, cb_>(w);
-        } else {
-            constexpr int r_ = p / (WIN - 1), c_ = p % (WIN - 1);
-            xa = px_at<r_, c_>(w); ya = px_at<r_ + 1, c_ + 1>(w);    // (r,c)-(r+1,c+1)
-            xb = px_at<r_, c_ + 1>(w); yb = px_at<r_ + 1, c_>(w);    // (r,c+1)-(r+1,c)
-        }
-        unsigned da, db;
-        const unsigned ka = pair_key(xa, ya, da), kb = pair_key(xb, yb, db);
-        K[p] = ka | (kb << 16);
-        pin32(K[p]);  // materialise the packed key now: otherwise the 4 min/max values per pair stay live until a
-                      // later key-assembly phase (4P registers)
-        HqA += hq[da];
-        HqB += hq[db];
-        // pin the two accumulation chains: left alone, the optimiser re-associates the 2P integer adds into
-        // a tree, which keeps all 2P 64-bit LUT values alive at once (4P registers -> one wave per SIMD)
+        // pixel positions of pair p in angle A (low half) and angle B (high half)
+        constexpr int rxa = G == 0 ? p / (WIN - 1) : p / (WIN - 1), cxa = G == 0 ? p % (WIN - 1) : p % (WIN - 1);
+        constexpr int rya = G == 0 ? rxa : rxa + 1, cya = cxa + 1;
+        constexpr int rxb = G == 0 ? p / WIN : p / (WIN - 1), cxb = G == 0 ? p % WIN : p % (WIN - 1) + 1;
+        constexpr int ryb = rxb + 1, cyb = G == 0 ? cxb : cxb - 1;
+        // v_perm_b32: result byte 0 <- angle-A pixel, byte 2 <- angle-B pixel, bytes 1 and 3 <- 0
+        constexpr unsigned selx = (unsigned)(cxa & 3) | (0x0cu << 8) | ((unsigned)(4 + (cxb & 3)) << 16) | (0x0cu << 24);
+        constexpr unsigned sely = (unsigned)(cya & 3) | (0x0cu << 8) | ((unsigned)(4 + (cyb & 3)) << 16) | (0x0cu << 24);
+        const unsigned x = __builtin_amdgcn_perm(w[rxb][cxb >> 2], w[rxa][cxa >> 2], selx);
+        const unsigned y = __builtin_amdgcn_perm(w[ryb][cyb >> 2], w[rya][cya >> 2], sely);
+        const unsigned lo = pk_min(x, y), hi = pk_max(x, y);
+        const unsigned d = pk_sub(hi, lo);
+        const unsigned one = 0x00010001u;
+        // key = diag << 12 | lo << 6 | hi, both halves at once
+        const unsigned diag = pk_sub(one, pk_min(d, one));
+        K[p] = pk_add(pk_add(pk_mul(lo, 0x00400040u), hi), pk_mul(diag, 0x10001000u));
+        pin32(K[p]);  // materialise the packed key now (short live ranges)
+        HqA += hq[d & 0xffffu];
+        HqB += hq[d >> 16];
         if constexpr (p % 6 == 5) {  // every 6 pairs: up to 12 LUT reads (24 registers) in flight, not 2P
             pin64(HqA);
             pin64(HqB);
