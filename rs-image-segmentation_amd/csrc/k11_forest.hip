@@ -10,8 +10,8 @@
 //   * the two children of a node are adjacent (left = c, right = c + 1): a node is 8 bytes
 //       { float thr ; uint32 : bits 0-23 left child (or leaf-value row), 24-29 feature, 30 missing->left, 31 leaf }
 //   * the first NTOP nodes of a tree are its upper levels: the workgroup copies that block into LDS
-//     (double-buffered, the copy of tree t+1 overlaps the walk of tree t) and only the levels below it
-//     are gathered from L2 / Infinity Cache.
+//     (double-buffered, the copy of the next pair of trees overlaps the walk of the current pair) and only
+//     the levels below it are gathered from L2 / Infinity Cache.
 // `X[i,f] <= threshold` compares a float32 feature with a float64 threshold; that is equivalent to
 // comparing with the threshold rounded DOWN to float32, which is what thr holds.
 // The pixel's features are staged once in LDS ([F][1024] floats, bank = lane, conflict-free for any
@@ -45,6 +45,38 @@ struct rf_tree {
     int pad;
 };
 
+// One step of a walk: from node `nd` of a tree whose first `lim` nodes are in LDS (`buf`), the rest in `tn`.
+template <int RF_THREADS>
+__device__ __forceinline__ rf_node rf_step(const rf_node nd, const float *__restrict__ feat, const rf_node *__restrict__ buf, int lim,
+                                           const rf_node *__restrict__ tn)
+{
+    const float x = feat[((nd.bits >> 24) & 63u) * RF_THREADS + threadIdx.x];
+    const unsigned left = nd.bits & 0xffffffu;
+    bool go_left;
+    if (x != x) go_left = (nd.bits & RF_MISS) != 0;
+    else go_left = x <= nd.thr;
+    const unsigned next = go_left ? left : left + 1u;
+    return (int)next < lim ? buf[next] : tn[next];
+}
+
+template <int NC>
+__device__ __forceinline__ void rf_vote(const rf_node nd, const rf_tree &tr, const double *__restrict__ leafval, int n_classes, double (&acc)[NC])
+{
+    if (nd.bits & RF_PURE) {
+        const int cls = (nd.bits >> 24) & 31u;
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] += (c == cls) ? 1.0 : 0.0;
+    } else {
+        const double *v = leafval + (size_t)(tr.leaf_off + (int)(nd.bits & 0xffffffu)) * n_classes;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (c < n_classes) acc[c] += v[c];
+    }
+}
+
+// Trees are walked TWO AT A TIME per pixel (independent dependency chains: the walk is a chain of dependent
+// LDS / L2 gathers, so a second chain nearly doubles what a wave keeps in flight); votes are still added in
+// tree order.  LDS: features + 2 x 2 top blocks (the pair being walked, the pair being copied in).
 template <int NC, int RF_THREADS>
 __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
                                                          const rf_tree *__restrict__ trees, int n_trees, int ntop,
@@ -53,66 +85,64 @@ __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, in
 {
     extern __shared__ __align__(16) char smem[];
     float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_THREADS]
-    rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_THREADS);       // [2][ntop]
+    rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_THREADS);       // [2 pairs][2 trees][ntop]
     const int64_t i = (int64_t)blockIdx.x * RF_THREADS + threadIdx.x;
     for (int f = 0; f < F; f++) feat[f * RF_THREADS + threadIdx.x] = i < n ? pl.p[f][i] : 0.f;
-    // tree 0's top block
-    {
-        const rf_tree t0 = trees[0];
+    constexpr int NPRE = 8192 / RF_THREADS;  // 2 * ntop <= 8192 nodes per pair
+    // pair 0's top blocks
+    for (int h = 0; h < 2 && h < n_trees; h++) {
+        const rf_tree t0 = trees[h];
         const int cnt = t0.n_nodes < ntop ? t0.n_nodes : ntop;
-        for (int j = threadIdx.x; j < cnt; j += RF_THREADS) top[j] = nodes[t0.node_off + j];
+        for (int j = threadIdx.x; j < cnt; j += RF_THREADS) top[(size_t)h * ntop + j] = nodes[t0.node_off + j];
     }
     __syncthreads();
     double acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) acc[c] = 0.0;
-    for (int t = 0; t < n_trees; t++) {
-        const rf_tree tr = trees[t];
-        const rf_node *buf = top + (size_t)(t & 1) * ntop;
-        // issue the copy of the next tree's top block (held in registers during the walk)
-        constexpr int NPRE = 8192 / RF_THREADS;  // ntop <= 8192
+    const int n_pairs = (n_trees + 1) / 2;
+    for (int pr = 0; pr < n_pairs; pr++) {
+        const int t = 2 * pr;
+        const bool two = t + 1 < n_trees;
+        const rf_tree trA = trees[t], trB = trees[two ? t + 1 : t];
+        const rf_node *bufA = top + (size_t)((pr & 1) * 2) * ntop, *bufB = bufA + ntop;
+        // issue the copy of the next pair's top blocks (held in registers during the walk)
         rf_node pre[NPRE];
-        int pcnt = 0, poff = 0;
-        if (t + 1 < n_trees) {
-            const rf_tree tn = trees[t + 1];
-            pcnt = tn.n_nodes < ntop ? tn.n_nodes : ntop;
-            poff = tn.node_off;
+        int cntA = 0, cntB = 0, offA = 0, offB = 0;
+        if (t + 2 < n_trees) {
+            const rf_tree tn = trees[t + 2];
+            cntA = tn.n_nodes < ntop ? tn.n_nodes : ntop;
+            offA = tn.node_off;
+            if (t + 3 < n_trees) {
+                const rf_tree tm = trees[t + 3];
+                cntB = tm.n_nodes < ntop ? tm.n_nodes : ntop;
+                offB = tm.node_off;
+            }
 #pragma unroll
             for (int r = 0; r < NPRE; r++) {
-                const int j = threadIdx.x + r * RF_THREADS;
-                if (j < pcnt) pre[r] = nodes[poff + j];
+                const int j = threadIdx.x + r * RF_THREADS;  // [0, 2*ntop): first the A block, then the B block
+                if (j < ntop) { if (j < cntA) pre[r] = nodes[offA + j]; }
+                else if (j - ntop < cntB) pre[r] = nodes[offB + (j - ntop)];
             }
         }
         if (i < n) {
-            const rf_node *tn = nodes + tr.node_off;
-            const int lim = tr.n_nodes < ntop ? tr.n_nodes : ntop;
-            rf_node nd = buf[0];
-            while (!(nd.bits & RF_LEAF)) {
-                const float x = feat[((nd.bits >> 24) & 63u) * RF_THREADS + threadIdx.x];
-                const unsigned left = nd.bits & 0xffffffu;
-                bool go_left;
-                if (x != x) go_left = (nd.bits & RF_MISS) != 0;
-                else go_left = x <= nd.thr;
-                const unsigned next = go_left ? left : left + 1u;
-                nd = (int)next < lim ? buf[next] : tn[next];
+            const rf_node *tnA = nodes + trA.node_off, *tnB = nodes + trB.node_off;
+            const int limA = trA.n_nodes < ntop ? trA.n_nodes : ntop, limB = trB.n_nodes < ntop ? trB.n_nodes : ntop;
+            rf_node a = bufA[0], b = two ? bufB[0] : a;
+            if (!two) b.bits = RF_LEAF;
+            while (!((a.bits & b.bits) & RF_LEAF)) {
+                if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS>(a, feat, bufA, limA, tnA);
+                if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS>(b, feat, bufB, limB, tnB);
             }
-            if (nd.bits & RF_PURE) {
-                const int cls = (nd.bits >> 24) & 31u;
-#pragma unroll
-                for (int c = 0; c < NC; c++) acc[c] += (c == cls) ? 1.0 : 0.0;
-            } else {
-                const double *v = leafval + (size_t)(tr.leaf_off + (int)(nd.bits & 0xffffffu)) * n_classes;
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    if (c < n_classes) acc[c] += v[c];
-            }
+            rf_vote<NC>(a, trA, leafval, n_classes, acc);
+            if (two) rf_vote<NC>(b, trB, leafval, n_classes, acc);
         }
-        if (t + 1 < n_trees) {
-            rf_node *nb = top + (size_t)((t + 1) & 1) * ntop;
+        if (t + 2 < n_trees) {
+            rf_node *nb = top + (size_t)(((pr + 1) & 1) * 2) * ntop;
 #pragma unroll
             for (int r = 0; r < NPRE; r++) {
                 const int j = threadIdx.x + r * RF_THREADS;
-                if (j < pcnt) nb[j] = pre[r];
+                if (j < ntop) { if (j < cntA) nb[j] = pre[r]; }
+                else if (j - ntop < cntB) nb[j] = pre[r];
             }
         }
         __syncthreads();
@@ -243,10 +273,10 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     // environment asks for 512 (experiments); LDS = features TH * F * 4 B + two top blocks of ntop 8-byte nodes
     int TH = 1024;
     if (const char *e = getenv("RSSEG_FOREST_THREADS")) TH = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : 1024);
-    int ntop = 8192;
-    while (ntop > 256 && (size_t)F * TH * 4 + 2 * (size_t)ntop * sizeof(rf_node) > 150 * 1024) ntop >>= 1;
+    int ntop = 4096;  // per tree; four blocks resident (two pairs)
+    while (ntop > 256 && (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node) > 150 * 1024) ntop >>= 1;
     if (const char *e = getenv("RSSEG_FOREST_NTOP")) ntop = std::min(ntop, std::max(256, atoi(e)));
-    const size_t lds = (size_t)F * TH * 4 + 2 * (size_t)ntop * sizeof(rf_node);
+    const size_t lds = (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node);
     const unsigned grid = (unsigned)ceil_div64(n, TH);
     auto launch = [&](auto kern) -> int {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
