@@ -326,17 +326,17 @@ template <typename T, int KMAX, int FR, bool UPDATE>
 __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k, int64_t n,
                                                        const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
                                                        const T *__restrict__ csq, uint8_t *__restrict__ labels,
-                                                       long long *__restrict__ partial, int64_t nchunks)
+                                                       long long *__restrict__ partial, int64_t nchunks, int ncopies)
 {
     constexpr int PXL = vt<T>::PXL;
     constexpr int TILE = KM_THREADS * PXL;
     extern __shared__ __align__(16) char smem[];
-    unsigned long long *S = reinterpret_cast<unsigned long long *>(smem);  // [COPIES][stride]
+    unsigned long long *S = reinterpret_cast<unsigned long long *>(smem);  // [ncopies][stride]
     const int stride = km_copy_stride(KMAX, F);
     const int lane = threadIdx.x & 63;
-    unsigned long long *myS = S + (size_t)(lane & (KM_COPIES - 1)) * stride;
+    unsigned long long *myS = S + (size_t)(lane & (ncopies - 1)) * stride;
     if (UPDATE) {
-        for (int i = threadIdx.x; i < KM_COPIES * stride; i += KM_THREADS) S[i] = 0ull;
+        for (int i = threadIdx.x; i < ncopies * stride; i += KM_THREADS) S[i] = 0ull;
         __syncthreads();
     }
     T cs[KMAX];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
             long long v;
             if (i < KMAX * F + KMAX) {
                 unsigned long long a = 0;
-                for (int c = 0; c < KM_COPIES; c++) a += S[(size_t)c * stride + i];
+                for (int c = 0; c < ncopies; c++) a += S[(size_t)c * stride + i];
                 v = (long long)a;
             } else {
                 v = changed_w[0] + changed_w[1] + changed_w[2] + changed_w[3];
@@ -719,7 +719,7 @@ i128 limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
 
 template <typename T, int KMAX, int FR>
 int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial)
+                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
 {
     if (update) {
         static size_t attr = 48 * 1024;  // default dynamic-LDS limit without the attribute
@@ -728,21 +728,21 @@ int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plan
             attr = lds;
         }
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks);
+                           cenT, csq, labels, partial, nchunks, ncopies);
     } else {
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks);
+                           cenT, csq, labels, partial, nchunks, ncopies);
     }
     return RSSEG_OK;
 }
 
 template <typename T, int KMAX>
 int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial)
+                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
 {
-    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
-    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
-    return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial);
+    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
+    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
+    return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
 }
 
 template <typename T, int NL, int FR>
@@ -1130,7 +1130,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const double t_init = now_ms();
 
     // ---- Lloyd (_kmeans_single_lloyd) ----
-    const size_t lds = sizeof(long long) * (size_t)KM_COPIES * km_copy_stride(KMAX, F);
+    // accumulator copies: 32 when they fit in ~48 KB (3 workgroups per CU), fewer for large k * F
+    int ncopies = KM_COPIES;
+    while (ncopies > 1 && sizeof(long long) * (size_t)ncopies * km_copy_stride(KMAX, F) > 48 * 1024) ncopies >>= 1;
+    const size_t lds = sizeof(long long) * (size_t)ncopies * km_copy_stride(KMAX, F);
     if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
     auto run_lloyd = [&](bool update) -> int {
         // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
@@ -1154,10 +1157,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 const size_t l2 = update ? lds : 0;
                 int lrc;
                 switch (KMAX) {
-                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
-                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part); break;
+                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
+                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
+                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
+                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
                 }
                 if (lrc != RSSEG_OK) return lrc;
             }

@@ -457,3 +457,20 @@ def test_kmeans_empty_cluster_relocation(ctx, oracle, seed):
         warnings.simplefilter("ignore")
         ref = KMeans(n_clusters=k, random_state=42, n_init="auto").fit_predict(MinMaxScaler().fit_transform(X))
     assert np.array_equal(host(labels), ref)
+
+
+@pytest.mark.parametrize("k,F,dt", [(12, 5, np.float32), (20, 20, np.float32), (40, 3, np.float32), (33, 9, np.float64), (2, 1, np.float32),
+                                    (1, 4, np.float32), (16, 32, np.float32)])
+def test_kmeans_many_clusters_and_features(ctx, oracle, k, F, dt):
+    """Every kernel instantiation (KMAX 8/16/32/64 x 8/16/32 register-resident features, float32 and float64)
+    against the oracle, on clumpy data so that the iteration count is non-trivial."""
+    rng = np.random.default_rng(k * 100 + F)
+    n = 20011
+    cent = rng.random((k + 3, F))
+    X = (cent[rng.integers(0, k + 3, n)] + rng.normal(0, 0.08, (n, F))).astype(dt)
+    planes = [np.ascontiguousarray(X[:, f]) for f in range(F)]
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    labels, meta = ctx.kmeans_fit_predict([dev(ctx, p) for p in planes], k)
+    assert np.array_equal(meta["init_indices"], info["init_indices"])
+    assert meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(host(labels), want)
