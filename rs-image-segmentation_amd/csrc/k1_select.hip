@@ -25,22 +25,35 @@ __device__ __forceinline__ uint32_t f32_key(float x, bool &is_nan)
 // Which table an element feeds is found with O(1) LDS byte lookups, not a scan of the live prefixes:
 // tab1[key >> 21] = slot of the 11-bit prefix (255 = not wanted); pass 2 adds tab2[slot1][(key >> 10) & 2047].
 #define SEL_NONE 255u
-template <int PASS>
-__global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__ x, int64_t n,
+// Counter / lookup position of bin b inside a 2048-entry table.  Integer-valued planes put all their keys on
+// multiples of 64 (the low mantissa bits are zero), i.e. on ONE LDS bank; folding bits 6..10 into bits 0..4 spreads
+// them over the banks.  An involution: swz(swz(b)) == b.
+__host__ __device__ __forceinline__ uint32_t swz(uint32_t b) { return b ^ (b >> 6); }
+
+// THREADS: 256, or 1024 so that the one set of tables a CU has room for (up to 82 KB) is shared by 16 waves.
+// BATCH: the LDS lookups of the 4*UNR values of a lane are issued back to back (one wait) instead of value by value.
+// (Merging the lanes of a wave that hit the same counter before the atomic was measured and does not pay.)
+// Pass 0 has LDS to spare and the most crowded counters (sign, exponent and two mantissa bits: a coherent image
+// region is ONE bin), so its table is replicated P0_COPIES times, copy = lane & 7 at an odd word stride.
+#define P0_COPIES 8
+#define P0_STRIDE (SEL_BINS + 1)
+template <int PASS, int THREADS, int UNR>
+__global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, int64_t n,
                                                        const uint32_t *__restrict__ prefixes, int nprefix,
                                                        unsigned long long *__restrict__ hist,
                                                        unsigned long long *__restrict__ nan_count)
 {
     extern __shared__ uint32_t lh[];  // [ntab][SEL_BINS] counters, then the byte lookup tables
     const int ntab = PASS == 0 ? 1 : nprefix;
-    const int nb = ntab * SEL_BINS;
+    const int nb = PASS == 0 ? P0_COPIES * P0_STRIDE : ntab * SEL_BINS;
+    const uint32_t my_copy = (threadIdx.x & (P0_COPIES - 1)) * P0_STRIDE;
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(lh + nb);  // [2048]
     uint8_t *tab2 = tab1 + SEL_BINS;                       // [n1][2048], pass 2 only
     __shared__ uint32_t p1list[RSSEG_MAX_RANKS];
     __shared__ int n1s;
-    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) lh[i] = 0;
+    for (int i = threadIdx.x; i < nb; i += THREADS) lh[i] = 0;
     if (PASS != 0) {
-        for (int i = threadIdx.x; i < SEL_BINS; i += SEL_THREADS) tab1[i] = SEL_NONE;
+        for (int i = threadIdx.x; i < SEL_BINS; i += THREADS) tab1[i] = SEL_NONE;
         if (threadIdx.x == 0) {
             int n1 = 0;  // distinct 11-bit prefixes
             for (int j = 0; j < nprefix; j++) {
@@ -53,7 +66,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__
         }
         __syncthreads();
         if (PASS == 2)
-            for (int i = threadIdx.x; i < n1s * SEL_BINS; i += SEL_THREADS) tab2[i] = SEL_NONE;
+            for (int i = threadIdx.x; i < n1s * SEL_BINS; i += THREADS) tab2[i] = SEL_NONE;
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int t = 0; t < n1s; t++) tab1[p1list[t]] = (uint8_t)t;
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__
             } else {
                 for (int j = 0; j < nprefix; j++) {
                     const uint32_t p1 = prefixes[j] >> 11, mid = prefixes[j] & 2047u;
-                    tab2[(size_t)tab1[p1] * SEL_BINS + mid] = (uint8_t)j;
+                    tab2[(size_t)tab1[p1] * SEL_BINS + swz(mid)] = (uint8_t)j;
                 }
             }
         }
@@ -74,33 +87,53 @@ __global__ __launch_bounds__(SEL_THREADS) void k1_hist(const float *__restrict__
     auto handle = [&](float v) {
         bool isn;
         uint32_t k = f32_key(v, isn);
-        if (isn) {
-            my_nan++;
-            return;
-        }
+        if (isn) my_nan++;
+        bool want = !isn;
+        uint32_t idx = 0;
         if (PASS == 0) {
-            atomicAdd(&lh[k >> 21], 1u);
+            idx = my_copy + swz(k >> 21);
         } else {
             const uint32_t s1 = tab1[k >> 21];
-            if (s1 != SEL_NONE) {
-                if (PASS == 1) {
-                    atomicAdd(&lh[s1 * SEL_BINS + ((k >> 10) & 2047u)], 1u);
-                } else {
-                    const uint32_t s2 = tab2[(size_t)s1 * SEL_BINS + ((k >> 10) & 2047u)];
-                    if (s2 != SEL_NONE) atomicAdd(&lh[s2 * SEL_BINS + (k & 1023u)], 1u);
-                }
+            want = want && s1 != SEL_NONE;
+            if (PASS == 1) {
+                idx = (want ? s1 : 0u) * SEL_BINS + swz((k >> 10) & 2047u);
+            } else {
+                const uint32_t s2 = want ? tab2[(size_t)s1 * SEL_BINS + swz((k >> 10) & 2047u)] : SEL_NONE;
+                want = want && s2 != SEL_NONE;
+                idx = (want ? s2 : 0u) * SEL_BINS + swz(k & 1023u);
             }
         }
+        if (want) atomicAdd(&lh[idx], 1u);
     };
-    for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * SEL_THREADS) {
-        float4 v = x4[i];
-        handle(v.x); handle(v.y); handle(v.z); handle(v.w);
+    {
+        const int64_t stride = (int64_t)gridDim.x * THREADS;
+        int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+        for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {  // UNR 16-byte loads in flight per lane
+            float4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) v[u] = x4[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { handle(v[u].x); handle(v[u].y); handle(v[u].z); handle(v[u].w); }
+        }
+        for (; i < n4; i += stride) {
+            float4 v = x4[i];
+            handle(v.x); handle(v.y); handle(v.z); handle(v.w);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) handle(x[(n4 << 2) + threadIdx.x]);
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += SEL_THREADS) {
-        uint32_t c = lh[i];
-        if (c) atomicAdd(&hist[i], (unsigned long long)c);
+    if (PASS == 0) {
+        for (int i = threadIdx.x; i < SEL_BINS; i += THREADS) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int cp = 0; cp < P0_COPIES; cp++) c += lh[cp * P0_STRIDE + i];
+            if (c) atomicAdd(&hist[swz(i)], (unsigned long long)c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nb; i += THREADS) {
+            uint32_t c = lh[i];
+            if (c) atomicAdd(&hist[(i & ~(SEL_BINS - 1)) + swz(i & (SEL_BINS - 1))], (unsigned long long)c);
+        }
     }
     if (PASS == 0) {
         uint32_t t = wave_sum(my_nan);
@@ -134,13 +167,32 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
     long long *h_hist = (long long *)ctx->h_pin;
 
     static bool attr_done = false;
+    static int sel_threads = 1024;
     const int SEL_BATCH = 8;  // live prefixes per launch: 8 * (8 KB counters + 2 KB lookup) + 2 KB of LDS
     if (!attr_done) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BATCH * SEL_BINS * 4 + SEL_BINS));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BATCH * SEL_BINS * 5 + SEL_BINS));
+        const char *ev = getenv("RSSEG_SEL_THREADS");
+        if (ev && atoi(ev) == 256) sel_threads = 256;
+        const int l1 = SEL_BATCH * SEL_BINS * 4 + SEL_BINS, l2 = SEL_BATCH * SEL_BINS * 5 + SEL_BINS, l0 = P0_COPIES * P0_STRIDE * 4;
+#define SEL_ATTR(TH)                                                                                                       \
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));    \
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));    \
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
+        SEL_ATTR(256) SEL_ATTR(1024)
         attr_done = true;
     }
-    int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, SEL_THREADS)));
+    const int threads = sel_threads;
+    int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
+    auto launch = [&](int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb) {
+#define SEL_GO(P, TH) hipLaunchKernelGGL((k1_hist<P, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan)
+#define SEL_PASS(TH)                         \
+    do {                                     \
+        if (pass == 0) SEL_GO(0, TH);        \
+        else if (pass == 1) SEL_GO(1, TH);   \
+        else SEL_GO(2, TH);                  \
+    } while (0)
+        if (threads == 256) SEL_PASS(256);
+        else SEL_PASS(1024);
+    };
     int64_t rem[RSSEG_MAX_RANKS];
     uint32_t prefix[RSSEG_MAX_RANKS];
     bool is_nan_rank[RSSEG_MAX_RANKS];
@@ -173,14 +225,10 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
             prof_scope ps(ctx, "select");
             const int nb_ = std::min(SEL_BATCH, ndp - b0);
             // counters + tab1 (+ tab2: at most nb_ distinct 11-bit prefixes)
-            const size_t lds = (size_t)nb_ * SEL_BINS * sizeof(uint32_t) + (pass == 0 ? 0 : SEL_BINS) + (pass == 2 ? (size_t)nb_ * SEL_BINS : 0);
+            const size_t lds = pass == 0 ? (size_t)P0_COPIES * P0_STRIDE * sizeof(uint32_t)
+                                        : (size_t)nb_ * SEL_BINS * sizeof(uint32_t) + SEL_BINS + (pass == 2 ? (size_t)nb_ * SEL_BINS : 0);
             unsigned long long *hb = d_hist + (size_t)b0 * SEL_BINS;
-            if (pass == 0)
-                hipLaunchKernelGGL(k1_hist<0>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre, 1, hb, d_nan);
-            else if (pass == 1)
-                hipLaunchKernelGGL(k1_hist<1>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre + b0, nb_, hb, d_nan);
-            else
-                hipLaunchKernelGGL(k1_hist<2>, dim3(grid), dim3(SEL_THREADS), lds, ctx->stream, d_x, n_local, d_pre + b0, nb_, hb, d_nan);
+            launch(pass, lds, pass == 0 ? d_pre : d_pre + b0, pass == 0 ? 1 : nb_, hb);
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, pass == 0 ? hist_bytes : used, hipMemcpyDeviceToHost, ctx->stream));

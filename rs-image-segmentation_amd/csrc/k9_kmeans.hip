@@ -199,7 +199,9 @@ template <typename T, int NL> struct kpp_out_t {
     T *p[NL];
 };
 
-template <typename T, int NL, int FR>
+// VAR (first pass only, NL == 1): the same sweep also produces the np.var numerators
+// partial[1 + f][chunk] = sum fixed(fl((xs-m)*(xs-m))), saving a separate pass over the F planes.
+template <typename T, int NL, int FR, bool VAR>
 __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t n, const scaler_t<T> *__restrict__ sp,
                                                      const double *__restrict__ candT, const double *__restrict__ cc, int L,
                                                      const T *__restrict__ closest_in, kpp_out_t<T, NL> out,
@@ -209,6 +211,9 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
     unsigned long long acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) acc[l] = 0;
+    long long vacc[VAR ? FR : 1];
+#pragma unroll
+    for (int f = 0; f < (VAR ? FR : 1); f++) vacc[f] = 0;
     const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
     auto tile_body = [&](auto full_t, int64_t base) {
         constexpr bool FULL = decltype(full_t)::value;
@@ -241,7 +246,12 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
                 for (int l = 0; l < NL; l++) cd[l] = candT[f * KPP_MAXL + l];
 #pragma unroll
                 for (int p = 0; p < PXL; p++) {
-                    const double y = (double)(scaled<T>(x[f][p], sc, mnv) - me);
+                    const T yt = scaled<T>(x[f][p], sc, mnv) - me;
+                    if constexpr (VAR) {
+                        const T dd = yt * yt;
+                        if (FULL || base + p < n) vacc[f] += to_fixed40((double)dd);
+                    }
+                    const double y = (double)yt;
                     yy[p] = fma(y, y, yy[p]);
 #pragma unroll
                     for (int l = 0; l < NL; l++) dot[l][p] = fma(cd[l], y, dot[l][p]);
@@ -293,6 +303,18 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
     if ((int)threadIdx.x < NL && (int)threadIdx.x < L)
         partial[(size_t)threadIdx.x * nchunks + blockIdx.x] =
             sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x];
+    if constexpr (VAR) {
+        __shared__ long long svar[4][FR];
+#pragma unroll
+        for (int f = 0; f < FR; f++) {
+            long long s = wave_sum(vacc[f]);
+            if (lane_id() == 0) svar[threadIdx.x >> 6][f] = s;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < F)
+            partial[(size_t)(1 + threadIdx.x) * nchunks + blockIdx.x] =
+                (unsigned long long)(svar[0][threadIdx.x] + svar[1][threadIdx.x] + svar[2][threadIdx.x] + svar[3][threadIdx.x]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -747,28 +769,35 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
 
 template <typename T, int NL, int FR>
 void launch_kpp3(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                 int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+                 int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
 {
     kpp_out_t<T, NL> o;
     for (int l = 0; l < NL; l++) o.p[l] = l < L ? outs[l] : nullptr;
-    hipLaunchKernelGGL((km_kpp<T, NL, FR>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest_in, o,
+    if constexpr (NL == 1) {
+        if (with_var) {
+            hipLaunchKernelGGL((km_kpp<T, NL, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L,
+                               closest_in, o, partial, nchunks);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((km_kpp<T, NL, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest_in, o,
                        partial, nchunks);
 }
 template <typename T, int NL>
 void launch_kpp2(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                 int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+                 int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
 {
-    if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
-    else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
-    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
 }
 template <typename T>
 void launch_kpp(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                int L, const T *closest_in, T *const *outs, unsigned long long *partial)
+                int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
 {
-    if (L <= 1) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
-    else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
-    else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial);
+    if (L <= 1) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
 }
 
 template <typename T, int KMAX>
@@ -824,7 +853,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
-                                              sizeof(long long) * KPP_MAXL * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
+                                              sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
                                               sizeof(long long) * 2 * (size_t)M, (size_t)65536});
     RSCHK(pin_reserve(ctx, pin_need));
     char *ws = ctx->d_ws;
@@ -918,27 +947,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         sp.mean[f] = m;
     }
     HIPCHK(ctx, hipMemcpyAsync(d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
-    RSCHK(moment_pass(1, sums));
-    T tol;
-    {
-        T var[RSSEG_MAX_FEATURES];
-        for (int f = 0; f < F; f++) {
-            volatile T s = fixed_to_T<T>(sums[f]);
-            volatile T v = s / Nt;
-            var[f] = v;
-        }
-        volatile T m = np_pairwise_sum<T>(var, F);
-        volatile T m2 = m / (T)F;
-        volatile T t = m2 * (T)tol_in;
-        tol = t;
-    }
+    T tol = (T)0;  // mean(np.var(X, axis=0)) * tol: the variance sums ride on the first k-means++ pass below
     if (info) {
         for (int f = 0; f < F; f++) {
             info->scale[f] = (double)sp.scale[f];
             info->min[f] = (double)sp.minv[f];
             info->mean[f] = (double)sp.mean[f];
         }
-        info->tol = (double)tol;
     }
 
     // ---- k-means++ (_kmeans.py:213-270) ----
@@ -983,7 +998,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         return RSSEG_OK;
     };
     // per-rank totals of the local chunk partials (row `row` of d_part), and the local prefix table
-    std::vector<unsigned long long> h_part((size_t)nchunks * KPP_MAXL);
+    std::vector<unsigned long long> h_part((size_t)nchunks * (size_t)std::max(KPP_MAXL, F + 1));
     auto pull_partials = [&](int rows) -> int {
         if (n > 0) {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)rows * nchunks, hipMemcpyDeviceToHost, st));
@@ -1022,11 +1037,33 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
             T *outs0[1] = {d_closest};
-            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, (const T *)nullptr, outs0, (unsigned long long *)d_part);
+            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, (const T *)nullptr, outs0, (unsigned long long *)d_part, true);
         }
         HIPCHK(ctx, hipGetLastError());
     }
-    RSCHK(pull_partials(1));
+    RSCHK(pull_partials(1 + F));
+    {   // np.var(X, axis=0) from rows 1..F of the partials
+        long long lim[2 * RSSEG_MAX_FEATURES];
+        for (int f = 0; f < F; f++) {
+            i128 s = 0;
+            if (n > 0)
+                for (int64_t c = 0; c < nchunks; c++) s += (long long)h_part[(size_t)(1 + f) * nchunks + c];
+            lim[2 * f] = (long long)(s >> 32);
+            lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
+        }
+        RSCHK(comm_allreduce_host(ctx, lim, 2 * F, RSSEG_I64, RSSEG_SUM));
+        T var[RSSEG_MAX_FEATURES];
+        for (int f = 0; f < F; f++) {
+            volatile T s = fixed_to_T<T>(limbs(lim[2 * f], lim[2 * f + 1]));
+            volatile T v = s / Nt;
+            var[f] = v;
+        }
+        volatile T m = np_pairwise_sum<T>(var, F);
+        volatile T m2 = m / (T)F;
+        volatile T t = m2 * (T)tol_in;
+        tol = t;
+        if (info) info->tol = (double)tol;
+    }
     u128 rank_tot[RSSEG_MAX_RANKS], total;
     RSCHK(global_total(0, rank_tot, &total));
     T current_pot = (T)((double)total * (1.0 / 1099511627776.0));

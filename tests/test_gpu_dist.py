@@ -22,6 +22,27 @@ def _free_port():
     return str(p)
 
 
+def _wait_all(procs, timeout=240):
+    """Wait for every rank; as soon as one fails (or the deadline passes) the others are killed, so a crashed rank
+    cannot leave its peers blocked in a collective."""
+    import time
+    t0 = time.time()
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                raise AssertionError(f"rank exit codes {codes}")
+            if all(c == 0 for c in codes):
+                return
+            if time.time() - t0 > timeout:
+                raise AssertionError(f"ranks still running after {timeout} s: {codes}")
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_equals_single_rank(ctx, oracle, golden_dir, tmp_path, world):
     from rsseg import pipeline as P
@@ -32,8 +53,7 @@ def test_sharded_equals_single_rank(ctx, oracle, golden_dir, tmp_path, world):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "gpu_shard", str(r), str(world), port, str(tmp_path)])
              for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    _wait_all(procs)
     # single rank, same code path
     H, W = bands.shape[1:]
     dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(7)]
@@ -69,8 +89,7 @@ def test_striped_config3_equals_single_gpu(ctx, oracle, tmp_path, world):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "gpu_striped_c3", str(r), str(world), port, str(tmp_path)])
              for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    _wait_all(procs)
     labels, meta, planes = P.config3(ctx, [ctx.to_device(bands[i].reshape(-1)) for i in range(7)], H, W, k, 7, 1, 3)
     want = labels.cpu().numpy()
     g0, g4 = planes[7].cpu().numpy(), planes[11].cpu().numpy()
