@@ -57,11 +57,12 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
 
 
 # algorithmic HBM bytes per pixel and launch of each kernel family
-def algorithmic_bytes_per_px(family, F, glcm_step):
+def algorithmic_bytes_per_px(family, F, glcm_step, k=8):
     return {
         "glcm": 4 + 20.0 / (glcm_step * glcm_step),   # read plane once, write 5 property maps
         "lloyd": 4 * F + 8,                            # F float32 features + label read/write
-        "kpp": 4 * F + 8,                              # F features + closest-distance read/write
+        # k passes: first centre reads F planes; round 1 also writes the closest plane; later rounds read + write it
+        "kpp": (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1),
         "select": 4,                                   # one radix pass over one float32 plane
         "indices": 20 + 28,                            # 5 bands in, 7 indices out
         "gram": 28, "project": 28 + 12, "resize": 8, "box": 8, "stencil": 8, "forest": 4 * F + 8,
@@ -69,8 +70,8 @@ def algorithmic_bytes_per_px(family, F, glcm_step):
 
 
 # kernel family -> name of its dominant kernel in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
-PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16>", "glcm": "k4_glcm_thread<7>",
-              "select": "k1_hist<0>", "indices": "k2_indices", "gram": "k3_gram", "project": "k3_project", "resize": "k5_resize"}
+PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7>",
+              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices", "gram": "k3_gram<7>", "project": "k3_project", "resize": "k5_resize"}
 
 
 def pmc_traffic_bytes(family, px):
@@ -212,7 +213,7 @@ def main():
             ms, cnt = fams[dom]
             per_launch_s = ms / cnt / 1e3
             px = H * W if dom != "glcm" else ((H - 7) // args.glcm_step + 1) * ((W - 7) // args.glcm_step + 1)
-            bpp = algorithmic_bytes_per_px(dom, F, args.glcm_step)
+            bpp = algorithmic_bytes_per_px(dom, F, args.glcm_step, k)
             achieved = px * bpp / per_launch_s / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_bytes(dom, px) if H == 16384 else None,

@@ -22,6 +22,8 @@ struct pca_args {
     const float *band[PCA_MAXB];
     float center[PCA_MAXB];
     double scale[PCA_MAXB];
+    double rinv[PCA_MAXB];  // RN(1 / scale)
+    int slow_div;           // a scale whose reciprocal trick is not provably exact: use the IEEE division
     int nb;
     int scaled;
     double fx_scale;  // 2^Q used for the fixed-point accumulation of x and x*x
@@ -30,8 +32,15 @@ struct pca_args {
 __device__ __forceinline__ float pca_x(const pca_args &a, int b, float v)
 {
     if (!a.scaled) return v;
-    float d = v - a.center[b];
-    return (float)((double)d / a.scale[b]);
+    const float d = v - a.center[b];
+    if (a.slow_div) return (float)((double)d / a.scale[b]);
+    // RN(d / s) without the ~35-instruction IEEE division sequence: q = RN(d * RN(1/s)) is a faithful quotient, the
+    // fma residual r = d - q*s is exact, and RN(q + r * RN(1/s)) is then the correctly rounded quotient (Markstein's
+    // theorem; it needs RN(1/s) and a significand of s that is not all ones — checked on the host).
+    const double s = a.scale[b], y = a.rinv[b];
+    const double q = (double)d * y;
+    const double r = fma(-q, s, (double)d);
+    return (float)fma(r, y, q);
 }
 
 __device__ __forceinline__ long long to_fixed_q(double x, double s)
@@ -40,51 +49,60 @@ __device__ __forceinline__ long long to_fixed_q(double x, double s)
     return __double_as_longlong(d) - __double_as_longlong(FX_MAGIC);
 }
 
-// partial[blk][PCA_NACC][2] ({hi, lo} 32-bit limb sums): sums of x_b (nb entries) then x_a*x_b for a <= b (row-major upper triangle)
+// partial[blk][PCA_NACC][2] ({hi, lo} 32-bit limb sums): sums of x_b (nb entries) then x_a*x_b for a <= b (row-major upper
+// triangle of a PCA_MAXB x PCA_MAXB matrix).  The accumulators take the raw bit patterns of fma(v, 2^Q, 1.5*2^52); the
+// constant bits(1.5*2^52) is subtracted once per thread (count * constant, modulo 2^64) instead of once per term.
+__host__ __device__ constexpr int pca_tri(int b, int c) { return PCA_MAXB + b * PCA_MAXB - b * (b - 1) / 2 + (c - b); }
+
+template <int NB>
 __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, long long *__restrict__ partial)
 {
-    long long acc[PCA_NACC];
+    unsigned long long acc[PCA_NACC];
 #pragma unroll
     for (int i = 0; i < PCA_NACC; i++) acc[i] = 0;
+    unsigned long long cnt = 0;
     const int64_t n4 = n >> 2;
     auto pixel = [&](const float *v) {
-        float x[PCA_MAXB];
+        float x[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) x[b] = b < a.nb ? pca_x(a, b, v[b]) : 0.0f;
-        int t = PCA_MAXB;
+        for (int b = 0; b < NB; b++) x[b] = pca_x(a, b, v[b]);
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) {
-            acc[b] += to_fixed_q((double)x[b], a.fx_scale);
+        for (int b = 0; b < NB; b++) {
+            acc[b] += (unsigned long long)__double_as_longlong(fma((double)x[b], a.fx_scale, FX_MAGIC));
 #pragma unroll
-            for (int c = b; c < PCA_MAXB; c++) {
-                // product of two float32 values is exact in float64
-                acc[t] += to_fixed_q((double)x[b] * (double)x[c], a.fx_scale);
-                t++;
-            }
+            for (int c = b; c < NB; c++)  // the product of two float32 values is exact in float64
+                acc[pca_tri(b, c)] += (unsigned long long)__double_as_longlong(fma((double)x[b] * (double)x[c], a.fx_scale, FX_MAGIC));
         }
+        cnt++;
     };
     for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
-        float4 v[PCA_MAXB];
+        float4 v[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++)
-            v[b] = b < a.nb ? reinterpret_cast<const float4 *>(a.band[b])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float p0[PCA_MAXB], p1[PCA_MAXB], p2[PCA_MAXB], p3[PCA_MAXB];
+        for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+        float p0[NB], p1[NB], p2[NB], p3[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+        for (int b = 0; b < NB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
         pixel(p0); pixel(p1); pixel(p2); pixel(p3);
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
     if (t < n) {
-        float p[PCA_MAXB];
+        float p[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) p[b] = b < a.nb ? a.band[b][t] : 0.0f;
+        for (int b = 0; b < NB; b++) p[b] = a.band[b][t];
         pixel(p);
     }
+    const unsigned long long bias = cnt * (unsigned long long)__double_as_longlong(FX_MAGIC);
     // per-thread sums stay below 2^61; split into 32-bit limbs before the cross-lane sums
     __shared__ long long sh[4][2 * PCA_NACC];
 #pragma unroll
     for (int i = 0; i < PCA_NACC; i++) {
-        long long hi = wave_sum(acc[i] >> 32), lo = wave_sum(acc[i] & 0xffffffffLL);
+        bool used = i < NB;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int c = b; c < NB; c++) used = used || i == pca_tri(b, c);
+        const long long v = used ? (long long)(acc[i] - bias) : 0ll;
+        long long hi = wave_sum(v >> 32), lo = wave_sum(v & 0xffffffffLL);
         if (lane_id() == 0) { sh[threadIdx.x >> 6][2 * i] = hi; sh[threadIdx.x >> 6][2 * i + 1] = lo; }
     }
     __syncthreads();
@@ -200,6 +218,10 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
         a.band[b] = d_bands[b];
         a.center[b] = center ? center[b] : 0.f;
         a.scale[b] = scale ? scale[b] : 1.0;
+        a.rinv[b] = 1.0 / a.scale[b];
+        uint64_t sb;
+        memcpy(&sb, &a.scale[b], 8);
+        if (!std::isnormal(a.scale[b]) || !std::isnormal(a.rinv[b]) || (sb & 0xfffffffffffffull) == 0xfffffffffffffull) a.slow_div = 1;
     }
     // bound on |x'| from the band ranges (one cheap pass would also do; the hot path feeds normalised
     // bands in [0,1], so bound with that and the scaler): |x'| <= max(|0-c|,|1-c|)/s
@@ -221,7 +243,11 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
     long long *d_part = (long long *)ctx->d_ws;
     {
         prof_scope ps(ctx, "gram");
-        hipLaunchKernelGGL(k3_gram, dim3(grid), dim3(PCA_THREADS), 0, ctx->stream, a, n_local, d_part);
+        switch (nb) {
+#define GRAM_GO(NBV) case NBV: hipLaunchKernelGGL(k3_gram<NBV>, dim3(grid), dim3(PCA_THREADS), 0, ctx->stream, a, n_local, d_part); break;
+            GRAM_GO(1) GRAM_GO(2) GRAM_GO(3) GRAM_GO(4) GRAM_GO(5) GRAM_GO(6) GRAM_GO(7) GRAM_GO(8)
+#undef GRAM_GO
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)grid * 2 * PCA_NACC, hipMemcpyDeviceToHost, ctx->stream));

@@ -183,31 +183,32 @@ __global__ void km_gather_row(planes_t pl, int F, int64_t idx, const scaler_t<T>
 }
 
 // ------------------------------------------------------------------------------------------------
-// k-means++ pass (_kmeans.py:225-262).  candT: [F][KPP_MAXL] candidate rows upcast to float64 (transposed: one
-// scalar load per feature brings all candidates), cc: [L] float64 squared norms.
-//   closest_in == nullptr (first centre):  out[0] = d2(cand0, x)
-//   otherwise (one sampling round):        out[l] = min(closest_in, d2(cand_l, x))   for l < L
-// and partial[l][chunk] = sum over the chunk of fixed(out[l]).  One workgroup per chunk
-// (km_chunk<T>() pixels), so partial[l][] is at once the potential of candidate l and the prefix table
-// used to locate the next sampled pixel (np.searchsorted on stable_cumsum, _kmeans.py:243-246).
-// After the host has picked the best candidate its out[] plane simply BECOMES the closest-distance plane
-// (pointer swap): one pass per round, 4F + 4 + 4L B/px, instead of an evaluation pass plus an update pass.
+// k-means++ pass (_kmeans.py:225-262).  candT: [F][KPP_STRIDE] rows upcast to float64 (transposed: one scalar
+// load per feature brings all of them): columns 0..L-1 are this round's candidates, column KPP_MAXL is the
+// PENDING centre (the one chosen in the previous round); cc: their float64 squared norms, same layout.
+//   MODE 0 (first centre):  partial[0][chunk] = sum fixed(d2(cand0, x)), and the np.var numerators
+//                           partial[1 + f][chunk] = sum fixed(fl((xs-m)*(xs-m))) ride on the same sweep;
+//                           nothing is written per pixel.
+//   MODE 1 (round 1):       closest <- d2(pending, x)
+//   MODE 2 (later rounds):  closest <- min(closest, d2(pending, x))            (np.minimum of the chosen candidate)
+//   MODE 1/2 then:          partial[l][chunk] = sum fixed(min(closest, d2(cand_l, x)))   for l < L
+// One workgroup per chunk (km_chunk<T>() pixels), so partial[l][] is at once the potential of candidate l and,
+// for the candidate the host picks, the prefix table used to locate the next sampled pixel (np.searchsorted on
+// stable_cumsum, _kmeans.py:243-246): the chosen candidate's min-plane is never stored, the next round
+// re-derives it as its pending update (same arithmetic, same bits) and km_kpp_chunk does so for the one chunk a
+// sample falls into.  Traffic per round: 4F + 8 B/px (read F planes + closest, write closest).
 // As in km_lloyd the F feature vectors of a lane's pixels are requested back to back into registers.
 // ------------------------------------------------------------------------------------------------
 #define KPP_MAXL 8
-template <typename T, int NL> struct kpp_out_t {
-    T *p[NL];
-};
+#define KPP_STRIDE (KPP_MAXL + 1)
 
-// VAR (first pass only, NL == 1): the same sweep also produces the np.var numerators
-// partial[1 + f][chunk] = sum fixed(fl((xs-m)*(xs-m))), saving a separate pass over the F planes.
-template <typename T, int NL, int FR, bool VAR>
+template <typename T, int NL, int FR, int MODE>
 __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t n, const scaler_t<T> *__restrict__ sp,
                                                      const double *__restrict__ candT, const double *__restrict__ cc, int L,
-                                                     const T *__restrict__ closest_in, kpp_out_t<T, NL> out,
-                                                     unsigned long long *__restrict__ partial, int64_t nchunks)
+                                                     T *__restrict__ closest, unsigned long long *__restrict__ partial, int64_t nchunks)
 {
     constexpr int PXL = vt<T>::PXL;
+    constexpr bool VAR = MODE == 0;
     unsigned long long acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) acc[l] = 0;
@@ -229,11 +230,12 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
         T cl[PXL];
 #pragma unroll
         for (int p = 0; p < PXL; p++) cl[p] = (T)0;
-        if (closest_in != nullptr) load_pxf<T, FULL>(closest_in, base, n, cl);
-        double dot[NL][PXL], yy[PXL];
+        if constexpr (MODE == 2) load_pxf<T, FULL>(closest, base, n, cl);
+        double dot[NL][PXL], dotp[PXL], yy[PXL];
 #pragma unroll
         for (int p = 0; p < PXL; p++) {
             yy[p] = 0.0;
+            dotp[p] = 0.0;
 #pragma unroll
             for (int l = 0; l < NL; l++) dot[l][p] = 0.0;
         }
@@ -241,9 +243,10 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
         for (int f = 0; f < FR; f++) {
             if (f < F) {
                 const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
-                double cd[NL];  // unconditional: candT is padded to KPP_MAXL columns (zeros beyond L)
+                double cd[NL];  // unconditional: candT rows are padded (zeros beyond L)
 #pragma unroll
-                for (int l = 0; l < NL; l++) cd[l] = candT[f * KPP_MAXL + l];
+                for (int l = 0; l < NL; l++) cd[l] = candT[f * KPP_STRIDE + l];
+                const double cdp = candT[f * KPP_STRIDE + KPP_MAXL];
 #pragma unroll
                 for (int p = 0; p < PXL; p++) {
                     const T yt = scaled<T>(x[f][p], sc, mnv) - me;
@@ -253,35 +256,47 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
                     }
                     const double y = (double)yt;
                     yy[p] = fma(y, y, yy[p]);
+                    if constexpr (MODE != 0) dotp[p] = fma(cdp, y, dotp[p]);
 #pragma unroll
                     for (int l = 0; l < NL; l++) dot[l][p] = fma(cd[l], y, dot[l][p]);
                 }
+            }
+        }
+        if constexpr (MODE != 0) {
+            const double ccp = cc[KPP_MAXL];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) {
+                double d = -2.0 * dotp[p];
+                d = d + ccp;
+                d = d + yy[p];
+                T dt = (T)d;
+                dt = dt > (T)0 ? dt : (T)0;
+                if constexpr (MODE == 2) dt = cl[p] < dt ? cl[p] : dt;
+                cl[p] = dt;
+            }
+            if (FULL || base + PXL <= n) {
+                typename vt<T>::vec o;
+                if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                else o = make_double2(cl[0], cl[1]);
+                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+            } else {
+                for (int p = 0; p < PXL; p++)
+                    if (base + p < n) closest[base + p] = cl[p];
             }
         }
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             if (l < L) {
                 const double ccl = cc[l];
-                T outv[PXL];
 #pragma unroll
                 for (int p = 0; p < PXL; p++) {
                     double d = -2.0 * dot[l][p];
                     d = d + ccl;
                     d = d + yy[p];
                     T dt = (T)d;
-                    dt = dt > (T)0 ? dt : (T)0;                                   // np.maximum(distances, 0)
-                    if (closest_in != nullptr) dt = cl[p] < dt ? cl[p] : dt;     // np.minimum(closest, d)
+                    dt = dt > (T)0 ? dt : (T)0;                               // np.maximum(distances, 0)
+                    if constexpr (MODE != 0) dt = cl[p] < dt ? cl[p] : dt;    // np.minimum(closest, d)
                     if (FULL || base + p < n) acc[l] += (unsigned long long)to_fixed40((double)dt);
-                    outv[p] = dt;
-                }
-                if (FULL || base + PXL <= n) {
-                    typename vt<T>::vec o;
-                    if constexpr (PXL == 4) o = make_float4(outv[0], outv[1], outv[2], outv[3]);
-                    else o = make_double2(outv[0], outv[1]);
-                    *reinterpret_cast<typename vt<T>::vec *>(out.p[l] + base) = o;
-                } else {
-                    for (int p = 0; p < PXL; p++)
-                        if (base + p < n) out.p[l][base + p] = outv[p];
                 }
             }
         }
@@ -314,6 +329,37 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
         if ((int)threadIdx.x < F)
             partial[(size_t)(1 + threadIdx.x) * nchunks + blockIdx.x] =
                 (unsigned long long)(svar[0][threadIdx.x] + svar[1][threadIdx.x] + svar[2][threadIdx.x] + svar[3][threadIdx.x]);
+    }
+}
+
+// The current closest-distance values of ONE chunk (the one a sample falls into), i.e. what the next km_kpp round
+// will store for it: out[i] = with_old ? min(closest[c0+i], d2(pending, x)) : d2(pending, x).  Same operation
+// sequence as km_kpp, so the same bits.
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void km_kpp_chunk(planes_t pl, int F, int64_t c0, int64_t cn, const scaler_t<T> *__restrict__ sp,
+                                                           const double *__restrict__ candT, const double *__restrict__ cc,
+                                                           const T *__restrict__ closest, int with_old, T *__restrict__ out)
+{
+    const double ccp = cc[KPP_MAXL];
+    for (int64_t i = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x; i < cn; i += (int64_t)gridDim.x * KM_THREADS) {
+        double yy = 0.0, dotp = 0.0;
+        for (int f = 0; f < F; f++) {
+            const T xv = reinterpret_cast<const T *>(pl.p[f])[c0 + i];
+            const T yt = scaled<T>(xv, sp->scale[f], sp->minv[f]) - sp->mean[f];
+            const double y = (double)yt;
+            yy = fma(y, y, yy);
+            dotp = fma(candT[f * KPP_STRIDE + KPP_MAXL], y, dotp);
+        }
+        double d = -2.0 * dotp;
+        d = d + ccp;
+        d = d + yy;
+        T dt = (T)d;
+        dt = dt > (T)0 ? dt : (T)0;
+        if (with_old) {
+            const T c = closest[c0 + i];
+            dt = c < dt ? c : dt;
+        }
+        out[i] = dt;
     }
 }
 
@@ -769,35 +815,33 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
 
 template <typename T, int NL, int FR>
 void launch_kpp3(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                 int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
+                 int L, int mode, T *closest, unsigned long long *partial)
 {
-    kpp_out_t<T, NL> o;
-    for (int l = 0; l < NL; l++) o.p[l] = l < L ? outs[l] : nullptr;
+#define KPP_GO(M) hipLaunchKernelGGL((km_kpp<T, NL, FR, M>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest, partial, nchunks)
     if constexpr (NL == 1) {
-        if (with_var) {
-            hipLaunchKernelGGL((km_kpp<T, NL, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L,
-                               closest_in, o, partial, nchunks);
-            return;
-        }
+        KPP_GO(0);
+    } else {
+        if (mode == 1) KPP_GO(1);
+        else KPP_GO(2);
     }
-    hipLaunchKernelGGL((km_kpp<T, NL, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest_in, o,
-                       partial, nchunks);
+#undef KPP_GO
 }
 template <typename T, int NL>
 void launch_kpp2(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                 int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
+                 int L, int mode, T *closest, unsigned long long *partial)
 {
-    if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
-    else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
-    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
+    else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
+    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
 }
+// mode 0: first centre (L == 1, no per-pixel output); 1: first sampling round; 2: later rounds
 template <typename T>
 void launch_kpp(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n, const scaler_t<T> *sp, const double *cand, const double *cc,
-                int L, const T *closest_in, T *const *outs, unsigned long long *partial, bool with_var = false)
+                int L, int mode, T *closest, unsigned long long *partial)
 {
-    if (L <= 1) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
-    else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
-    else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, closest_in, outs, partial, with_var);
+    if (mode == 0) launch_kpp2<T, 1>(ctx, nchunks, pl, F, n, sp, cand, cc, 1, 0, closest, partial);
+    else if (L <= 4) launch_kpp2<T, 4>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
+    else launch_kpp2<T, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
 }
 
 template <typename T, int KMAX>
@@ -841,15 +885,16 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_sp = carve(sizeof(scaler_t<T>));
     const size_t o_cen = carve(sizeof(T) * KMAX * RSSEG_MAX_FEATURES);
     const size_t o_csq = carve(sizeof(T) * KMAX);
-    const size_t o_cand = carve(sizeof(double) * KPP_MAXL * RSSEG_MAX_FEATURES);
-    const size_t o_cc = carve(sizeof(double) * KPP_MAXL);
+    const size_t o_cand = carve(sizeof(double) * KPP_STRIDE * RSSEG_MAX_FEATURES);
+    const size_t o_cc = carve(sizeof(double) * KPP_STRIDE);
     const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
     const size_t o_red = carve(sizeof(long long) * 2 * M);
     const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
     const size_t o_mom = carve(sizeof(long long) * (size_t)nblk * F);
     const size_t o_part = carve(sizeof(long long) * std::max<size_t>((size_t)M, KPP_MAXL) * (size_t)nchunks);
     const size_t dist_stride = (sizeof(T) * (size_t)std::max<int64_t>(n, 1) + 255) & ~(size_t)255;
-    const size_t o_closest = carve(dist_stride * (size_t)(L + 1));
+    const size_t o_closest = carve(dist_stride);            // the ONE closest-distance plane of k-means++
+    const size_t o_chunk = carve(sizeof(T) * (size_t)CHUNK);  // current closest values of the chunk a sample falls into
     const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
@@ -867,9 +912,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     T *d_mm = (T *)(ws + o_mm);
     long long *d_mom = (long long *)(ws + o_mom);
     long long *d_part = (long long *)(ws + o_part);
-    T *d_dist[KPP_MAXL + 1];  // L + 1 distance planes: the current closest-distance plane and L candidate planes
-    for (int l = 0; l <= L; l++) d_dist[l] = (T *)(ws + o_closest + dist_stride * (size_t)l);
-    T *d_closest = d_dist[0];
+    T *d_closest = (T *)(ws + o_closest);
+    T *d_chunk = (T *)(ws + o_chunk);
     uint8_t *d_lab = (uint8_t *)(ws + o_lab);
     hipStream_t st = ctx->stream;
 
@@ -980,20 +1024,24 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             for (int f = 0; f < F; f++) rows[l][f] = (T)buf[l * F + f];
         return RSSEG_OK;
     };
-    auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt) -> int {
-        double flat[KPP_MAXL * RSSEG_MAX_FEATURES];
-        double cc[KPP_MAXL];
+    // candidate rows (columns 0..cnt-1) and the pending centre (column KPP_MAXL; may be null) as float64, transposed
+    auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt, const T *pending) -> int {
+        double flat[KPP_STRIDE * RSSEG_MAX_FEATURES];
+        double cc[KPP_STRIDE];
         memset(flat, 0, sizeof(flat));
-        for (int l = 0; l < cnt; l++) {
+        memset(cc, 0, sizeof(cc));
+        auto put = [&](const T *row, int col) {
             double a = 0.0;
             for (int f = 0; f < F; f++) {
-                flat[f * KPP_MAXL + l] = (double)rows[l][f];
-                a = std::fma((double)rows[l][f], (double)rows[l][f], a);
+                flat[f * KPP_STRIDE + col] = (double)row[f];
+                a = std::fma((double)row[f], (double)row[f], a);
             }
-            cc[l] = a;
-        }
-        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(double) * KPP_MAXL * F, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(d_cc, cc, sizeof(double) * cnt, hipMemcpyHostToDevice, st));
+            cc[col] = a;
+        };
+        for (int l = 0; l < cnt; l++) put(rows[l], l);
+        if (pending) put(pending, KPP_MAXL);
+        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(double) * KPP_STRIDE * F, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_cc, cc, sizeof(double) * KPP_STRIDE, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));  // flat/cc live on this stack frame
         return RSSEG_OK;
     };
@@ -1033,11 +1081,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
         RSCHK(fetch_rows(init_idx, 1, rows));
         for (int f = 0; f < F; f++) C[0][f] = rows[0][f];
-        RSCHK(upload_cands(rows, 1));
+        RSCHK(upload_cands(rows, 1, nullptr));
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
-            T *outs0[1] = {d_closest};
-            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, (const T *)nullptr, outs0, (unsigned long long *)d_part, true);
+            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, 0, d_closest, (unsigned long long *)d_part);
         }
         HIPCHK(ctx, hipGetLastError());
     }
@@ -1070,8 +1117,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     std::vector<unsigned long long> prefix_part((size_t)nchunks);  // this rank's closest-dist chunk sums
     for (int64_t c = 0; c < nchunks; c++) prefix_part[c] = h_part[c];
 
-    T *cand_planes[KPP_MAXL] = {nullptr};
     for (int c = 1; c < k; c++) {
+        // centre c-1 is pending: its distances are folded into the closest plane by this round's pass, and by
+        // km_kpp_chunk for the chunks the samples fall into
+        RSCHK(upload_cands(nullptr, 0, C[c - 1]));
         int64_t cand_idx[KPP_MAXL];
         double found[KPP_MAXL];
         for (int l = 0; l < L; l++) {
@@ -1099,7 +1148,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             }
             if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
             const int64_t c0 = ch * CHUNK, cn = std::min<int64_t>(CHUNK, n - c0);
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_closest + c0, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL((km_kpp_chunk<T>), dim3((unsigned)ceil_div64(cn, KM_THREADS)), dim3(KM_THREADS), 0, st, pl, F, c0, cn, d_sp, d_cand,
+                               d_cc, (const T *)d_closest, c > 1 ? 1 : 0, d_chunk);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_chunk, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             const T *hv = (const T *)ctx->h_pin;
             int64_t li = cn - 1;
@@ -1113,16 +1165,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         for (int l = 0; l < L; l++) cand_idx[l] = (int64_t)found[l];
         T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
         RSCHK(fetch_rows(cand_idx, L, rows));
-        RSCHK(upload_cands(rows, L));
+        RSCHK(upload_cands(rows, L, C[c - 1]));
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
-            T *outs[KPP_MAXL];
-            for (int l = 0, sl = 0; l < L; l++, sl++) {
-                if (d_dist[sl] == d_closest) sl++;
-                outs[l] = d_dist[sl];
-            }
-            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, L, (const T *)d_closest, outs, (unsigned long long *)d_part);
-            for (int l = 0; l < L; l++) cand_planes[l] = outs[l];
+            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, L, c > 1 ? 2 : 1, d_closest, (unsigned long long *)d_part);
         }
         HIPCHK(ctx, hipGetLastError());
         RSCHK(pull_partials(L));
@@ -1156,8 +1202,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         current_pot = best_pot;
         for (int f = 0; f < F; f++) C[c][f] = rows[best][f];
         init_idx[c] = cand_idx[best];
-        // the best candidate's plane becomes the closest-distance plane; its chunk sums the prefix table
-        if (n > 0) d_closest = cand_planes[best];
+        // the best candidate's chunk sums become the prefix table (its min-plane is re-derived by the next round)
         for (int r = 0; r < ctx->world; r++) rank_tot[r] = rt_all[best][r];
         total = tot_all[best];
         for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[(size_t)best * nchunks + cc2];
