@@ -118,46 +118,47 @@ struct proj_args {
     int nc;
 };
 
+// Specialised on the band count; the component loop stays rolled so that only one component's coefficients are
+// held in scalar registers at a time (with everything unrolled the two argument blocks no longer fit the SGPR file).
+template <int NB>
 __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args pr, int64_t n)
 {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
-        float4 v[PCA_MAXB];
+        float4 v[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++)
-            v[b] = b < a.nb ? reinterpret_cast<const float4 *>(a.band[b])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float x[4][PCA_MAXB];
+        for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+        float x[4][NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) {
-            x[0][b] = b < a.nb ? pca_x(a, b, v[b].x) : 0.f;
-            x[1][b] = b < a.nb ? pca_x(a, b, v[b].y) : 0.f;
-            x[2][b] = b < a.nb ? pca_x(a, b, v[b].z) : 0.f;
-            x[3][b] = b < a.nb ? pca_x(a, b, v[b].w) : 0.f;
+        for (int b = 0; b < NB; b++) {
+            x[0][b] = pca_x(a, b, v[b].x);
+            x[1][b] = pca_x(a, b, v[b].y);
+            x[2][b] = pca_x(a, b, v[b].z);
+            x[3][b] = pca_x(a, b, v[b].w);
         }
+#pragma nounroll
+        for (int c = 0; c < pr.nc; c++) {
+            float y[4];
 #pragma unroll
-        for (int c = 0; c < PCA_MAXB; c++) {
-            if (c < pr.nc) {
-                float y[4];
+            for (int p = 0; p < 4; p++) {
+                float s = 0.f;
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int b = 0; b < PCA_MAXB; b++)
-                        if (b < a.nb) s = __fmaf_rn(x[p][b], pr.comp[c][b], s);
-                    y[p] = s - pr.offs[c];
-                }
-                reinterpret_cast<float4 *>(pr.out[c])[i] = make_float4(y[0], y[1], y[2], y[3]);
+                for (int b = 0; b < NB; b++) s = __fmaf_rn(x[p][b], pr.comp[c][b], s);
+                y[p] = s - pr.offs[c];
             }
+            reinterpret_cast<float4 *>(pr.out[c])[i] = make_float4(y[0], y[1], y[2], y[3]);
         }
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
     if (t < n) {
-        float x[PCA_MAXB];
+        float x[NB];
 #pragma unroll
-        for (int b = 0; b < PCA_MAXB; b++) x[b] = b < a.nb ? pca_x(a, b, a.band[b][t]) : 0.f;
+        for (int b = 0; b < NB; b++) x[b] = pca_x(a, b, a.band[b][t]);
+#pragma nounroll
         for (int c = 0; c < pr.nc; c++) {
             float s = 0.f;
-            for (int b = 0; b < a.nb; b++) s = __fmaf_rn(x[b], pr.comp[c][b], s);
+#pragma unroll
+            for (int b = 0; b < NB; b++) s = __fmaf_rn(x[b], pr.comp[c][b], s);
             pr.out[c][t] = s - pr.offs[c];
         }
     }
@@ -337,8 +338,12 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
     if (d_out && n_local > 0) {
         {
             prof_scope ps(ctx, "project");
-            hipLaunchKernelGGL(k3_project, dim3((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS)))),
-                               dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local);
+            const dim3 pg((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
+            switch (nb) {
+#define PROJ_GO(NBV) case NBV: hipLaunchKernelGGL(k3_project<NBV>, pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local); break;
+                PROJ_GO(1) PROJ_GO(2) PROJ_GO(3) PROJ_GO(4) PROJ_GO(5) PROJ_GO(6) PROJ_GO(7) PROJ_GO(8)
+#undef PROJ_GO
+            }
         }
         HIPCHK(ctx, hipGetLastError());
     }

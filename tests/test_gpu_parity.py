@@ -198,6 +198,23 @@ def test_glcm_bitexact_vs_oracle(ctx, oracle, win, step):
         assert np.array_equal(host(g, (oh, ow)), want[k]), (k, win, step)
 
 
+def test_glcm_dense_sliding_kernel_bitexact_vs_oracle(ctx, oracle):
+    """Dense 7x7 / step 1 / 32 levels on a map wider than one strip (128 columns) and taller than one wave (64 rows,
+    last wave partial): the sliding-window kernel against the oracle, all five properties bit for bit."""
+    rng = np.random.default_rng(77)
+    H, W = 150, 300
+    base = rng.integers(0, 32, (H, W))
+    smooth = (np.add.outer(np.arange(H), 2 * np.arange(W)) // 11) % 32
+    q = np.where(rng.random((H, W)) < 0.4, base, smooth).astype(np.uint8)
+    q[40:70, 100:160] = 31  # flat region: every pair on one diagonal bin (largest counter values)
+    q[90:110, :] = (np.arange(W) % 2 * 31).astype(np.uint8)  # two-level stripes
+    want = oracle.glcm_small_maps(q, 32, 7, 1, mode=1)
+    got, (oh, ow) = ctx.glcm(dev(ctx, q), H, W, 32, 7, 1)
+    assert (oh, ow) == (144, 294)
+    for g, k in zip(got, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
+        assert np.array_equal(host(g, (oh, ow)), want[k]), k
+
+
 def test_resize_bilinear_bitexact_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(5)
     for (sh, sw, dh, dw) in [(28, 28, 600, 600), (13, 7, 40, 55), (594, 594, 600, 600), (1, 1, 8, 8), (5, 9, 5, 9)]:
