@@ -52,21 +52,35 @@ struct glcm_group {
     double sq;  // sqrt(A_a) + sqrt(A_b)
 };
 
-__device__ __forceinline__ void glcm_finish(const glcm_group &g0, const glcm_group &g1, long long na, long long nb, double r0,
-                                            double r1, double r2, double r3, size_t o, const glcm_out &out)
+// RN(a / b) for a divisor known on the host: with y = RN(1/b), q = RN(a*y) is a faithful quotient, the fma residual
+// r = a - q*b is exact and RN(q + r*y) is the correctly rounded quotient (Markstein) - three instructions instead of
+// the ~12-instruction IEEE sequence.  The host checks the precondition (significand of b not all ones).
+__device__ __forceinline__ double div_const(double a, double b, double y)
 {
-    const double dna = (double)na, dnb = (double)nb, den4 = (double)(4 * na * nb), den8 = (double)(8 * na * nb);
-    if (out.p[0]) out.p[0][o] = (float)((double)(g0.S2 * nb + g1.S2 * na) / den4);
-    if (out.p[1]) out.p[1][o] = (float)((double)(g0.S1 * nb + g1.S1 * na) / den4);
+    const double q = a * y;
+    const double r = fma(-q, b, a);
+    return fma(r, y, q);
+}
+
+struct glcm_consts {
+    double den4, den8, rden4, rden8;  // 4*na*nb, 8*na*nb and their correctly rounded reciprocals
+};
+
+__device__ __forceinline__ void glcm_finish(const glcm_group &g0, const glcm_group &g1, long long na, long long nb, double r0,
+                                            double r1, double r2, double r3, size_t o, const glcm_out &out, const glcm_consts &gc)
+{
+    const double dna = (double)na, dnb = (double)nb;
+    if (out.p[0]) out.p[0][o] = (float)div_const((double)(g0.S2 * nb + g1.S2 * na), gc.den4, gc.rden4);
+    if (out.p[1]) out.p[1][o] = (float)div_const((double)(g0.S1 * nb + g1.S1 * na), gc.den4, gc.rden4);
     if (out.p[2]) {
         const double t1 = (double)g1.Hq * dna;
         const double num = fma((double)g0.Hq, dnb, t1);
-        out.p[2][o] = (float)((num / den4) * (1.0 / 4503599627370496.0));
+        out.p[2][o] = (float)(div_const(num, gc.den4, gc.rden4) * (1.0 / 4503599627370496.0));
     }
     if (out.p[3]) {
         const double t1 = g1.sq * dna;
         const double num = fma(g0.sq, dnb, t1);
-        out.p[3][o] = (float)(num / den8);
+        out.p[3][o] = (float)div_const(num, gc.den8, gc.rden8);
     }
     if (out.p[4]) out.p[4][o] = (float)((((r0 + r1) + r2) + r3) * 0.25);
 }
@@ -117,6 +131,16 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
+// v_pk_min_u16 the optimiser cannot see through: min(x, 1) written in C++ is canonicalised to a compare + select,
+// which has no packed form and costs four instructions per register instead of one.
+__device__ __forceinline__ unsigned pk_min_opaque(unsigned a, unsigned b)
+{
+    unsigned r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+#endif
+    return r;
+}
 __device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
@@ -129,9 +153,9 @@ __device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, b)));
 }
-__device__ __forceinline__ unsigned pk_shr12(unsigned a)
+template <int N> __device__ __forceinline__ unsigned pk_shr(unsigned a)
 {
-    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) >> (us2)(12)));
+    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) >> (us2)(N)));
 }
 
 // window rows packed 4 pixels per register: w[r][0] = px 0..3, w[r][1] = px 4..7 (zero beyond WIN-1)
@@ -208,10 +232,14 @@ __device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned 
 
 // One angle group: G = 0 -> angles 0 (0,1) and 90 (1,0) degrees, G = 1 -> 45 (1,1) and 135 (1,-1).
 // Both angles of a group have the same pair count P, so their keys share registers (low / high half).
-template <int WIN, int G>
+// The window holds the pixels PRE-SCALED by 2^SH (SH = 3 for levels <= 32, 2 for levels <= 64: still one byte), so
+// that |a-b| << SH is at once the byte offset into the 8-byte Hq table (SH = 3) and all sums are exact multiples
+// that are shifted back at the end.  Key = diag << (10+SH) | lo' << (8-SH) | hi'  (primed = scaled) < 2^16.
+template <int WIN, int G, int SH>
 __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_group &g,
                                                  double &ra, double &rb)
 {
+    constexpr unsigned MUL_LO = (1u << (8 - SH)) * 0x00010001u, DIAG_BIT = (1u << (10 + SH)) * 0x00010001u;
     constexpr int P = G == 0 ? WIN * (WIN - 1) : (WIN - 1) * (WIN - 1);
     unsigned K[P];
     long long HqA = 0, HqB = 0;
@@ -230,12 +258,12 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         const unsigned lo = pk_min(x, y), hi = pk_max(x, y);
         const unsigned d = pk_sub(hi, lo);
         const unsigned one = 0x00010001u;
-        // key = diag << 12 | lo << 6 | hi, both halves at once
-        const unsigned diag = pk_sub(one, pk_min(d, one));
-        K[p] = pk_add(pk_add(pk_mul(lo, 0x00400040u), hi), pk_mul(diag, 0x10001000u));
+        // key = offdiag << (10+SH) | lo' << (8-SH) | hi', both halves at once (offdiag = 1 unless a == b)
+        const unsigned nd = pk_min_opaque(d, one);
+        K[p] = pk_add(pk_add(pk_mul(lo, MUL_LO), hi), pk_mul(nd, DIAG_BIT));
         pin32(K[p]);  // materialise the packed key now (short live ranges)
-        HqA += hq[d & 0xffffu];
-        HqB += hq[d >> 16];
+        HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d & 0xffffu) << (3 - SH)));
+        HqB += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d >> 16) << (3 - SH)));
         if constexpr (p % 6 == 5) {  // every 6 pairs: up to 12 LUT reads (24 registers) in flight, not 2P
             pin64(HqA);
             pin64(HqB);
@@ -259,20 +287,23 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         K[ib] = pk_max(ka, kb);
     });
     __builtin_amdgcn_sched_barrier(0);
-    // packed run-length: t = equal-to-previous ? t + w : 0 ; E2 += t ; D += diag   (all < 2^16)
-    const unsigned one = 0x00010001u;
-    unsigned E2 = 0, t = 0, D = pk_shr12(K[0]);
+    // packed run-length: t = equal-to-previous ? t + w : 0 (w = 2 on the diagonal, else 1); E2 += t; ND += offdiag
+    const unsigned one = 0x00010001u, two = 0x00020002u;
+    unsigned E2 = 0, t = 0, ND = pk_shr<10 + SH>(K[0]);
     static_for<P - 1>([&](auto I) {
         constexpr int i = I + 1;
-        const unsigned diag = pk_shr12(K[i]);
-        const unsigned ne = pk_min(K[i] ^ K[i - 1], one);  // 0 where equal, 1 where different
-        const unsigned eq = pk_sub(one, ne);
-        t = pk_mul(pk_add(t, pk_add(diag, one)), eq);
+        const unsigned nd = pk_shr<10 + SH>(K[i]);
+        const unsigned ne = pk_min_opaque(K[i] ^ K[i - 1], one);  // 0 where equal, 1 where different
+        const unsigned keep = pk_sub(ne, one);                    // 0xffff where equal, 0 where different
+        t = pk_sub(t + two, nd) & keep;                           // all fields < 2^16: the plain add cannot carry across
         E2 = pk_add(E2, t);
-        D = pk_add(D, diag);
+        ND = pk_add(ND, nd);
     });
-    const long long Aa = 2ll * (P + (int)(D & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
-    const long long Ab = 2ll * (P + (int)(D >> 16)) + 4ll * (long long)(E2 >> 16);
+    const long long Aa = 2ll * (2 * P - (int)(ND & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
+    const long long Ab = 2ll * (2 * P - (int)(ND >> 16)) + 4ll * (long long)(E2 >> 16);
+    // undo the 2^SH pre-scaling (exact: every term is a multiple)
+    S1a >>= SH; S1b >>= SH; M1a >>= SH; M1b >>= SH;
+    XYa >>= 2 * SH; XYb >>= 2 * SH; M2a >>= 2 * SH; M2b >>= 2 * SH;
     g.S1 = (long long)S1a + (long long)S1b;
     g.S2 = ((long long)M2a - 2ll * XYa) + ((long long)M2b - 2ll * XYb);
     g.Hq = HqA + HqB;
@@ -295,9 +326,9 @@ template <int WIN> __device__ __forceinline__ void opaque_window(unsigned (&w)[8
 #endif
 }
 
-template <int WIN>
+template <int WIN, int SH>
 __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict__ q, int H, int W, int step, int oh, int ow,
-                                                      glcm_out out)
+                                                      glcm_out out, glcm_consts gc)
 {
     __shared__ long long hq[256];
     hq[threadIdx.x] = c_glcm_hq[threadIdx.x];
@@ -314,8 +345,8 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
             static_for<WIN>([&](auto J) {
                 constexpr int c = J;
                 const unsigned b = wp[(size_t)r * W + c];
-                if constexpr (c < 4) lo |= b << (8 * c);
-                else hi |= b << (8 * (c - 4));
+                if constexpr (c < 4) lo |= b << (8 * c + SH);  // pre-scaled by 2^SH (see glcm_group_stats)
+                else hi |= b << (8 * (c - 4) + SH);
             });
             w[r][0] = lo;
             w[r][1] = hi;
@@ -326,15 +357,15 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
 #pragma nounroll
     for (int g = 0; g < 2; g++) {
         opaque_window<WIN>(w);
-        if (g == 0) glcm_group_stats<WIN, 0>(w, hq, g0, r0, r2);
-        else glcm_group_stats<WIN, 1>(w, hq, g1, r1, r3);
+        if (g == 0) glcm_group_stats<WIN, 0, SH>(w, hq, g0, r0, r2);
+        else glcm_group_stats<WIN, 1, SH>(w, hq, g1, r1, r3);
     }
-    glcm_finish(g0, g1, (long long)WIN * (WIN - 1), (long long)(WIN - 1) * (WIN - 1), r0, r1, r2, r3, (size_t)oy * ow + ox, out);
+    glcm_finish(g0, g1, (long long)WIN * (WIN - 1), (long long)(WIN - 1) * (WIN - 1), r0, r1, r2, r3, (size_t)oy * ow + ox, out, gc);
 }
 
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
 __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q, int H, int W, int levels, int win, int step,
-                                                  int oh, int ow, glcm_out out)
+                                                  int oh, int ow, glcm_out out, glcm_consts gc)
 {
     extern __shared__ unsigned int hist[];  // levels*levels
     __shared__ long long red[4][8];
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q,
         double r[4];
         for (int a = 0; a < 4; a++) r[a] = glcm_corr(sst[a][0], sst[a][4], sst[a][5], sst[a][6]);
         glcm_finish(g0, g1, (long long)win * (win - 1), (long long)(win - 1) * (win - 1), r[0], r[1], r[2], r[3],
-                    (size_t)oy * ow + ox, out);
+                    (size_t)oy * ow + ox, out, gc);
     }
 }
 
@@ -408,16 +439,32 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         prof_scope ps(ctx, "glcm");
         const dim3 tg((ow + 63) / 64, (oh + 3) / 4);
         if (levels > 64) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: levels > 64 not supported");
-        if (win == 7)
-            hipLaunchKernelGGL(k4_glcm_thread<7>, tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out);
-        else if (win == 5)
-            hipLaunchKernelGGL(k4_glcm_thread<5>, tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out);
-        else if (win == 3)
-            hipLaunchKernelGGL(k4_glcm_thread<3>, tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out);
+        glcm_consts gc;
+        {
+            const long long na = (long long)win * (win - 1), nb = (long long)(win - 1) * (win - 1);
+            gc.den4 = (double)(4 * na * nb);
+            gc.den8 = (double)(8 * na * nb);
+            gc.rden4 = 1.0 / gc.den4;
+            gc.rden8 = 1.0 / gc.den8;
+            // div_const needs a divisor whose significand is not all ones: true for these small integers, checked anyway
+            for (double dv : {gc.den4, gc.den8}) {
+                uint64_t b;
+                memcpy(&b, &dv, 8);
+                if ((b & 0xfffffffffffffull) == 0xfffffffffffffull) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: window size %d not supported", win);
+            }
+        }
+#define GLCM_THREAD(WN)                                                                                                           \
+    do {                                                                                                                          \
+        if (levels <= 32) hipLaunchKernelGGL((k4_glcm_thread<WN, 3>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc); \
+        else hipLaunchKernelGGL((k4_glcm_thread<WN, 2>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc);          \
+    } while (0)
+        if (win == 7) GLCM_THREAD(7);
+        else if (win == 5) GLCM_THREAD(5);
+        else if (win == 3) GLCM_THREAD(3);
         else {
             if (ow > 2147483647 || oh > 65535) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: output map too tall for the workgroup-per-window kernel");
             hipLaunchKernelGGL(k4_glcm_wg, dim3(ow, oh), dim3(256), sizeof(unsigned int) * levels * levels, ctx->stream, d_q, H, W,
-                               levels, win, step, oh, ow, out);
+                               levels, win, step, oh, ow, out, gc);
         }
     }
     HIPCHK(ctx, hipGetLastError());
