@@ -27,6 +27,7 @@
 #include "common.h"
 
 __constant__ long long c_glcm_hq[256];
+__device__ long long g_glcm_hq2[1024];  // pair sums hq[dA] + hq[dB] at [dB * 32 + dA] (levels <= 32)
 
 static const int H_DR[4] = {0, 1, 1, 1};
 static const int H_DC[4] = {1, 1, 0, -1};
@@ -193,13 +194,13 @@ __device__ __forceinline__ unsigned pair_key(int x, int y, unsigned &d)
 
 // pair moments of one angle from whole packed rows: S1 = sum|a-b|, XY = sum ab, M2 = sum a^2+b^2, M1 = sum a+b
 template <int WIN, int DR, int DC>
-__device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned &S1, unsigned &XY, unsigned &M2, unsigned &M1)
+__device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned &S1, unsigned &XY)
 {
     constexpr int NB = DC == 0 ? WIN : WIN - 1;  // bytes taking part per row
     constexpr unsigned KLO = NB >= 4 ? 0xffffffffu : ((1u << (8 * (NB & 3))) - 1u);
     constexpr unsigned KHI = NB <= 4 ? 0u : ((NB >= 8) ? 0xffffffffu : ((1u << (8 * (NB - 4))) - 1u));
     constexpr int R1 = DR > 0 ? WIN - 1 : WIN;
-    S1 = XY = M2 = M1 = 0;
+    S1 = XY = 0;
     static_for<R1>([&](auto I) {
         constexpr int r = I;
         const unsigned a0 = w[r][0], a1 = w[r][1], b0 = w[r + DR][0], b1 = w[r + DR][1];
@@ -215,19 +216,79 @@ __device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned 
         }
         S1 = __builtin_amdgcn_sad_u8(Alo, Blo, S1);
         XY = __builtin_amdgcn_udot4(Alo, Blo, XY, false);
-        M2 = __builtin_amdgcn_udot4(Alo, Alo, M2, false);
-        M2 = __builtin_amdgcn_udot4(Blo, Blo, M2, false);
-        M1 = __builtin_amdgcn_sad_u8(Alo, 0u, M1);
-        M1 = __builtin_amdgcn_sad_u8(Blo, 0u, M1);
         if constexpr (WIN > 4) {
             S1 = __builtin_amdgcn_sad_u8(Ahi, Bhi, S1);
             XY = __builtin_amdgcn_udot4(Ahi, Bhi, XY, false);
-            M2 = __builtin_amdgcn_udot4(Ahi, Ahi, M2, false);
-            M2 = __builtin_amdgcn_udot4(Bhi, Bhi, M2, false);
-            M1 = __builtin_amdgcn_sad_u8(Ahi, 0u, M1);
-            M1 = __builtin_amdgcn_sad_u8(Bhi, 0u, M1);
         }
     });
+}
+
+// M1 = sum(a+b) and M2 = sum(a^2+b^2) over the pairs of each angle, from sums the four angles share: with T the
+// window total, R0/RL the first/last row, C0/CL the first/last column and the corners (L = WIN-1),
+//   0 deg   (r,c)-(r,c+1):    2T - C0 - CL
+//   90 deg  (r,c)-(r+1,c):    2T - R0 - RL
+//   45 deg  (r,c)-(r+1,c+1):  2T - R0 - RL - C0 - CL + w00 + wLL
+//   135 deg (r,c)-(r+1,c-1):  2T - R0 - RL - C0 - CL + w0L + wL0
+// and the same with squares (a pixel is the first member of a pair unless it lies in the last row/column the angle
+// excludes, the second member unless it lies in the first).  m1[] / m2[] are indexed 0, 45, 90, 135 degrees.
+template <int WIN> __device__ __forceinline__ void window_m1m2(const unsigned (&w)[8][2], unsigned (&m1)[4], unsigned (&m2)[4])
+{
+    constexpr int L = WIN - 1;
+    unsigned rs[WIN], rq[WIN];
+    static_for<WIN>([&](auto I) {
+        constexpr int r = I;
+        rs[r] = __builtin_amdgcn_sad_u8(w[r][0], 0u, 0u);
+        rq[r] = __builtin_amdgcn_udot4(w[r][0], w[r][0], 0u, false);
+        if constexpr (WIN > 4) {
+            rs[r] = __builtin_amdgcn_sad_u8(w[r][1], 0u, rs[r]);
+            rq[r] = __builtin_amdgcn_udot4(w[r][1], w[r][1], rq[r], false);
+        }
+    });
+    unsigned T = 0, T2 = 0;
+    static_for<WIN>([&](auto I) { T += rs[I]; T2 += rq[I]; });
+    // first / last column gathered into packed registers (rows 0..3, rows 4..)
+    constexpr unsigned s0 = 0x0c0c0400u;                                         // byte 0 of both operands
+    constexpr unsigned sl = 0x0c0c0000u | ((4u + (L & 3)) << 8) | (unsigned)(L & 3);  // byte L&3 of both operands
+    auto column = [&](auto lastc, unsigned &lo, unsigned &hi) {
+        constexpr bool LAST = decltype(lastc)::value;
+        constexpr int k = LAST ? (L >> 2) : 0;
+        constexpr unsigned sel = LAST ? sl : s0;
+        // __builtin_amdgcn_perm(hi_src, lo_src, sel): selector bytes 0..3 pick from lo_src, 4..7 from hi_src
+        const unsigned p01 = __builtin_amdgcn_perm(w[1 < WIN ? 1 : 0][k], w[0][k], sel);
+        const unsigned p23 = WIN > 2 ? __builtin_amdgcn_perm(w[3 < WIN ? 3 : 0][k], w[2 < WIN ? 2 : 0][k], sel) : 0u;
+        lo = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        if constexpr (WIN == 3) lo &= 0x00ffffffu;
+        hi = 0u;
+        if constexpr (WIN > 4) {
+            const unsigned p45 = __builtin_amdgcn_perm(w[5 < WIN ? 5 : 0][k], w[4][k], sel);
+            const unsigned p6 = WIN > 6 ? __builtin_amdgcn_perm(0u, w[6 < WIN ? 6 : 0][k], LAST ? (0x0c0c0c00u | (unsigned)(L & 3)) : 0x0c0c0c00u) : 0u;
+            hi = __builtin_amdgcn_perm(p6, p45, 0x05040100u);
+            if constexpr (WIN == 5) hi &= 0x000000ffu;
+        }
+    };
+    unsigned c0lo, c0hi, cllo, clhi;
+    column(std::false_type{}, c0lo, c0hi);
+    column(std::true_type{}, cllo, clhi);
+    unsigned C0 = __builtin_amdgcn_sad_u8(c0lo, 0u, 0u), CL = __builtin_amdgcn_sad_u8(cllo, 0u, 0u);
+    unsigned C0q = __builtin_amdgcn_udot4(c0lo, c0lo, 0u, false), CLq = __builtin_amdgcn_udot4(cllo, cllo, 0u, false);
+    if constexpr (WIN > 4) {
+        C0 = __builtin_amdgcn_sad_u8(c0hi, 0u, C0);
+        CL = __builtin_amdgcn_sad_u8(clhi, 0u, CL);
+        C0q = __builtin_amdgcn_udot4(c0hi, c0hi, C0q, false);
+        CLq = __builtin_amdgcn_udot4(clhi, clhi, CLq, false);
+    }
+    const unsigned w00 = c0lo & 0xffu, w0L = cllo & 0xffu;
+    const unsigned wL0 = WIN > 4 ? (c0hi >> (8 * (L - 4))) & 0xffu : (c0lo >> (8 * L)) & 0xffu;
+    const unsigned wLL = WIN > 4 ? (clhi >> (8 * (L - 4))) & 0xffu : (cllo >> (8 * L)) & 0xffu;
+    const unsigned R = rs[0] + rs[L], Rq = rq[0] + rq[L], C = C0 + CL, Cq = C0q + CLq;
+    m1[0] = 2 * T - C;
+    m1[2] = 2 * T - R;
+    m1[1] = 2 * T - R - C + w00 + wLL;
+    m1[3] = 2 * T - R - C + w0L + wL0;
+    m2[0] = 2 * T2 - Cq;
+    m2[2] = 2 * T2 - Rq;
+    m2[1] = 2 * T2 - Rq - Cq + w00 * w00 + wLL * wLL;
+    m2[3] = 2 * T2 - Rq - Cq + w0L * w0L + wL0 * wL0;
 }
 
 // One angle group: G = 0 -> angles 0 (0,1) and 90 (1,0) degrees, G = 1 -> 45 (1,1) and 135 (1,-1).
@@ -235,14 +296,18 @@ __device__ __forceinline__ void row_moments(const unsigned (&w)[8][2], unsigned 
 // The window holds the pixels PRE-SCALED by 2^SH (SH = 3 for levels <= 32, 2 for levels <= 64: still one byte), so
 // that |a-b| << SH is at once the byte offset into the 8-byte Hq table (SH = 3) and all sums are exact multiples
 // that are shifted back at the end.  Key = diag << (10+SH) | lo' << (8-SH) | hi'  (primed = scaled) < 2^16.
+struct glcm_raw {  // what one angle group leaves behind (S1 / XY still carry the 2^SH pre-scaling)
+    unsigned S1, XYa, XYb;
+    long long Hq;
+    double sq;
+};
 template <int WIN, int G, int SH>
-__device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_group &g,
-                                                 double &ra, double &rb)
+__device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_raw &g)
 {
     constexpr unsigned MUL_LO = (1u << (8 - SH)) * 0x00010001u, DIAG_BIT = (1u << (10 + SH)) * 0x00010001u;
     constexpr int P = G == 0 ? WIN * (WIN - 1) : (WIN - 1) * (WIN - 1);
     unsigned K[P];
-    long long HqA = 0, HqB = 0;
+    long long HqA = 0, HqB = 0;  // SH == 3: hq is the 32 x 32 table of PAIR sums hq[dB][dA] = Hq(dA) + Hq(dB): one read per register
     static_for<P>([&](auto I) {
         constexpr int p = I;
         // pixel positions of pair p in angle A (low half) and angle B (high half)
@@ -262,21 +327,27 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         const unsigned nd = pk_min_opaque(d, one);
         K[p] = pk_add(pk_add(pk_mul(lo, MUL_LO), hi), pk_mul(nd, DIAG_BIT));
         pin32(K[p]);  // materialise the packed key now (short live ranges)
-        HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d & 0xffffu) << (3 - SH)));
-        HqB += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d >> 16) << (3 - SH)));
+        if constexpr (SH == 3) {
+            // d = 8*dA | (8*dB) << 16  ->  byte offset 8 * (dA + 32 * dB)
+            const unsigned off = (d >> 11) | (d & 0xffu);  // the two fields do not overlap: v_lshrrev + v_and_or
+            HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + off);
+        } else {
+            HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d & 0xffffu) << (3 - SH)));
+            HqB += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d >> 16) << (3 - SH)));
+        }
         if constexpr (p % 6 == 5) {  // every 6 pairs: up to 12 LUT reads (24 registers) in flight, not 2P
             pin64(HqA);
             pin64(HqB);
         }
     });
     __builtin_amdgcn_sched_barrier(0);  // phase boundaries keep the phases' live ranges from overlapping
-    unsigned S1a, XYa, M2a, M1a, S1b, XYb, M2b, M1b;
+    unsigned S1a, XYa, S1b, XYb;
     if constexpr (G == 0) {
-        row_moments<WIN, 0, 1>(w, S1a, XYa, M2a, M1a);
-        row_moments<WIN, 1, 0>(w, S1b, XYb, M2b, M1b);
+        row_moments<WIN, 0, 1>(w, S1a, XYa);
+        row_moments<WIN, 1, 0>(w, S1b, XYb);
     } else {
-        row_moments<WIN, 1, 1>(w, S1a, XYa, M2a, M1a);
-        row_moments<WIN, 1, -1>(w, S1b, XYb, M2b, M1b);
+        row_moments<WIN, 1, 1>(w, S1a, XYa);
+        row_moments<WIN, 1, -1>(w, S1b, XYb);
     }
     __builtin_amdgcn_sched_barrier(0);
     // sort both halves at once
@@ -301,15 +372,11 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
     });
     const long long Aa = 2ll * (2 * P - (int)(ND & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
     const long long Ab = 2ll * (2 * P - (int)(ND >> 16)) + 4ll * (long long)(E2 >> 16);
-    // undo the 2^SH pre-scaling (exact: every term is a multiple)
-    S1a >>= SH; S1b >>= SH; M1a >>= SH; M1b >>= SH;
-    XYa >>= 2 * SH; XYb >>= 2 * SH; M2a >>= 2 * SH; M2b >>= 2 * SH;
-    g.S1 = (long long)S1a + (long long)S1b;
-    g.S2 = ((long long)M2a - 2ll * XYa) + ((long long)M2b - 2ll * XYb);
+    g.S1 = S1a + S1b;
+    g.XYa = XYa;
+    g.XYb = XYb;
     g.Hq = HqA + HqB;
     g.sq = sqrt((double)Aa) + sqrt((double)Ab);
-    ra = glcm_corr(P, M1a, M2a, 2ll * XYa);
-    rb = glcm_corr(P, M1b, M2b, 2ll * XYb);
 }
 
 // compiler fence: the packed window is redefined (as far as the compiler can tell) at the top of every
@@ -330,8 +397,12 @@ template <int WIN, int SH>
 __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict__ q, int H, int W, int step, int oh, int ow,
                                                       glcm_out out, glcm_consts gc)
 {
-    __shared__ long long hq[256];
-    hq[threadIdx.x] = c_glcm_hq[threadIdx.x];
+    __shared__ long long hq[SH == 3 ? 1024 : 256];
+    if constexpr (SH == 3) {
+        for (int i = threadIdx.x; i < 1024; i += 256) hq[i] = g_glcm_hq2[i];
+    } else {
+        hq[threadIdx.x] = c_glcm_hq[threadIdx.x];
+    }
     __syncthreads();
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -352,15 +423,33 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
             w[r][1] = hi;
         });
     }
-    glcm_group g0, g1;
-    double r0 = 1.0, r1 = 1.0, r2 = 1.0, r3 = 1.0;
+    glcm_raw q0, q1;
 #pragma nounroll
     for (int g = 0; g < 2; g++) {
         opaque_window<WIN>(w);
-        if (g == 0) glcm_group_stats<WIN, 0, SH>(w, hq, g0, r0, r2);
-        else glcm_group_stats<WIN, 1, SH>(w, hq, g1, r1, r3);
+        if (g == 0) glcm_group_stats<WIN, 0, SH>(w, hq, q0);
+        else glcm_group_stats<WIN, 1, SH>(w, hq, q1);
     }
-    glcm_finish(g0, g1, (long long)WIN * (WIN - 1), (long long)(WIN - 1) * (WIN - 1), r0, r1, r2, r3, (size_t)oy * ow + ox, out, gc);
+    // M1 / M2 of the four angles (computed after the groups: nothing of it has to stay live across them), then the
+    // 2^SH pre-scaling is undone (exact: every term is a multiple)
+    opaque_window<WIN>(w);
+    unsigned m1[4], m2[4];
+    window_m1m2<WIN>(w, m1, m2);
+    constexpr long long NA = (long long)WIN * (WIN - 1), NB = (long long)(WIN - 1) * (WIN - 1);
+    const long long xy0 = q0.XYa >> (2 * SH), xy90 = q0.XYb >> (2 * SH), xy45 = q1.XYa >> (2 * SH), xy135 = q1.XYb >> (2 * SH);
+    const long long M20 = m2[0] >> (2 * SH), M245 = m2[1] >> (2 * SH), M290 = m2[2] >> (2 * SH), M2135 = m2[3] >> (2 * SH);
+    glcm_group g0, g1;
+    g0.S1 = q0.S1 >> SH;
+    g0.S2 = (M20 - 2ll * xy0) + (M290 - 2ll * xy90);
+    g0.Hq = q0.Hq;
+    g0.sq = q0.sq;
+    g1.S1 = q1.S1 >> SH;
+    g1.S2 = (M245 - 2ll * xy45) + (M2135 - 2ll * xy135);
+    g1.Hq = q1.Hq;
+    g1.sq = q1.sq;
+    const double r0 = glcm_corr(NA, m1[0] >> SH, M20, 2ll * xy0), r1 = glcm_corr(NB, m1[1] >> SH, M245, 2ll * xy45);
+    const double r2 = glcm_corr(NA, m1[2] >> SH, M290, 2ll * xy90), r3 = glcm_corr(NB, m1[3] >> SH, M2135, 2ll * xy135);
+    glcm_finish(g0, g1, NA, NB, r0, r1, r2, r3, (size_t)oy * ow + ox, out, gc);
 }
 
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
@@ -430,6 +519,9 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         long long lut[256];
         for (int d = 0; d < 256; d++) lut[d] = llrint(4503599627370496.0 / (1.0 + (double)d * (double)d));
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_glcm_hq), lut, sizeof(lut)));
+        static long long lut2[1024];
+        for (int i = 0; i < 1024; i++) lut2[i] = lut[i & 31] + lut[i >> 5];
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_glcm_hq2), lut2, sizeof(lut2)));
         g_hq_ready[ctx->device & 63] = true;
     }
     const int oh = (H - win) / step + 1, ow = (W - win) / step + 1;
