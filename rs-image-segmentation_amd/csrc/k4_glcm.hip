@@ -142,6 +142,15 @@ __device__ __forceinline__ unsigned pk_min_opaque(unsigned a, unsigned b)
 #endif
     return r;
 }
+// max(a - b, 0) on both 16-bit halves (v_pk_sub_u16 with the clamp bit): 1 - d saturates to [d == 0]
+__device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b)
+{
+    unsigned r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+#endif
+    return r;
+}
 __device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
@@ -294,8 +303,9 @@ template <int WIN> __device__ __forceinline__ void window_m1m2(const unsigned (&
 // One angle group: G = 0 -> angles 0 (0,1) and 90 (1,0) degrees, G = 1 -> 45 (1,1) and 135 (1,-1).
 // Both angles of a group have the same pair count P, so their keys share registers (low / high half).
 // The window holds the pixels PRE-SCALED by 2^SH (SH = 3 for levels <= 32, 2 for levels <= 64: still one byte), so
-// that |a-b| << SH is at once the byte offset into the 8-byte Hq table (SH = 3) and all sums are exact multiples
-// that are shifted back at the end.  Key = diag << (10+SH) | lo' << (8-SH) | hi'  (primed = scaled) < 2^16.
+// that the scaled |a-b| gives the byte offset into the Hq table without a shift and all sums are exact multiples
+// that are shifted back at the end.  Key = lo' << 8 | hi' | diag (primed = scaled: the low SH bits of a scaled
+// value are zero, so bit 0 is free for the flag [a == b]): one v_lshl_or and one v_or on both halves at once.
 struct glcm_raw {  // what one angle group leaves behind (S1 / XY still carry the 2^SH pre-scaling)
     unsigned S1, XYa, XYb;
     long long Hq;
@@ -304,7 +314,6 @@ struct glcm_raw {  // what one angle group leaves behind (S1 / XY still carry th
 template <int WIN, int G, int SH>
 __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], const long long *__restrict__ hq, glcm_raw &g)
 {
-    constexpr unsigned MUL_LO = (1u << (8 - SH)) * 0x00010001u, DIAG_BIT = (1u << (10 + SH)) * 0x00010001u;
     constexpr int P = G == 0 ? WIN * (WIN - 1) : (WIN - 1) * (WIN - 1);
     unsigned K[P];
     long long HqA = 0, HqB = 0;  // SH == 3: hq is the 32 x 32 table of PAIR sums hq[dB][dA] = Hq(dA) + Hq(dB): one read per register
@@ -323,13 +332,13 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         const unsigned lo = pk_min(x, y), hi = pk_max(x, y);
         const unsigned d = pk_sub(hi, lo);
         const unsigned one = 0x00010001u;
-        // key = offdiag << (10+SH) | lo' << (8-SH) | hi', both halves at once (offdiag = 1 unless a == b)
-        const unsigned nd = pk_min_opaque(d, one);
-        K[p] = pk_add(pk_add(pk_mul(lo, MUL_LO), hi), pk_mul(nd, DIAG_BIT));
+        const unsigned diag = pk_sub_sat(one, d);  // [a == b] in both halves
+        K[p] = ((lo << 8) | hi) | diag;            // each half stays below 2^16: the 32-bit shift does not cross
         pin32(K[p]);  // materialise the packed key now (short live ranges)
         if constexpr (SH == 3) {
             // d = 8*dA | (8*dB) << 16  ->  byte offset 8 * (dA + 32 * dB)
-            const unsigned off = (d >> 11) | (d & 0xffu);  // the two fields do not overlap: v_lshrrev + v_and_or
+            // byte offset 8 * (dA + 32 * dB) = lo16(d) * 1 + hi16(d) * 32 in one v_dot2_u32_u16
+            const unsigned off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, d), (us2){1, 32}, 0u, false);
             HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + off);
         } else {
             HqA += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + ((d & 0xffffu) << (3 - SH)));
@@ -358,20 +367,21 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
         K[ib] = pk_max(ka, kb);
     });
     __builtin_amdgcn_sched_barrier(0);
-    // packed run-length: t = equal-to-previous ? t + w : 0 (w = 2 on the diagonal, else 1); E2 += t; ND += offdiag
-    const unsigned one = 0x00010001u, two = 0x00020002u;
-    unsigned E2 = 0, t = 0, ND = pk_shr<10 + SH>(K[0]);
+    // packed run-length: t = equal-to-previous ? t + w : 0 (w = 2 on the diagonal, else 1); E2 += t; D += diag.
+    // All fields stay far below 2^16, so plain 32-bit adds (v_add3_u32) serve both halves.
+    const unsigned one = 0x00010001u;
+    unsigned E2 = 0, t = 0, D = K[0] & one;
     static_for<P - 1>([&](auto I) {
         constexpr int i = I + 1;
-        const unsigned nd = pk_shr<10 + SH>(K[i]);
+        const unsigned diag = K[i] & one;
         const unsigned ne = pk_min_opaque(K[i] ^ K[i - 1], one);  // 0 where equal, 1 where different
         const unsigned keep = pk_sub(ne, one);                    // 0xffff where equal, 0 where different
-        t = pk_sub(t + two, nd) & keep;                           // all fields < 2^16: the plain add cannot carry across
-        E2 = pk_add(E2, t);
-        ND = pk_add(ND, nd);
+        t = (t + one + diag) & keep;
+        E2 += t;
+        D += diag;
     });
-    const long long Aa = 2ll * (2 * P - (int)(ND & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
-    const long long Ab = 2ll * (2 * P - (int)(ND >> 16)) + 4ll * (long long)(E2 >> 16);
+    const long long Aa = 2ll * (P + (int)(D & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
+    const long long Ab = 2ll * (P + (int)(D >> 16)) + 4ll * (long long)(E2 >> 16);
     g.S1 = S1a + S1b;
     g.XYa = XYa;
     g.XYb = XYb;
