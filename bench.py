@@ -70,8 +70,8 @@ def algorithmic_bytes_per_px(family, F, glcm_step, k=8):
 
 
 # kernel family -> name of its dominant kernel in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
-PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7>",
-              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices", "gram": "k3_gram<7>", "project": "k3_project", "resize": "k5_resize"}
+PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7, 3>",
+              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices", "gram": "k3_gram<7>", "project": "k3_project<7>", "resize": "k5_resize"}
 
 
 def pmc_traffic_bytes(family, px):
