@@ -149,6 +149,20 @@ int rsseg_box_mean_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, in
 int rsseg_local_std_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
 /* cv2.morphologyEx(MORPH_GRADIENT, ones(k,k)) on uint8 (indices.py:422, 433); output uint8. */
 int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, uint8_t *d_out);
+/* cv2.erode / cv2.dilate / cv2.morphologyEx(MORPH_OPEN | MORPH_CLOSE | MORPH_GRADIENT) with ones(k,k) on uint8
+ * (calculate_morphological_features, indices.py:421-433): k in {3,5,7}, default border (out-of-image taps never win),
+ * opening = dilate(erode(x)), closing = erode(dilate(x)).  Output uint8 (the caller divides by 255.0, :436-440). */
+#define RSSEG_MORPH_ERODE 0
+#define RSSEG_MORPH_DILATE 1
+#define RSSEG_MORPH_OPEN 2
+#define RSSEG_MORPH_CLOSE 3
+#define RSSEG_MORPH_GRADIENT 4
+int rsseg_morph_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out);
+/* variance_scale_k (indices.py:541-544): max(blur(x*x) - blur(x)^2, 0), REFLECT_101 (rsseg_local_std_f32 without the sqrt). */
+int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
+/* 'laplacian' of calculate_filter_responses (indices.py:472-474): cv2.Laplacian(u8, CV_32F) (3x3 cross, REFLECT_101)
+ * / 255.0, then (l - min) / (max - min + 1e-10) in float32; the global min / max go through the all-reduce hook. */
+int rsseg_laplacian_norm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out);
 /* sobel_mag (indices.py:477-480): 3x3 Sobel x/y of the uint8 plane as float32 / 255, magnitude,
  * divided by (global max + 1e-10).  Two launches; the global max goes through the all-reduce hook. */
 int rsseg_sobel_mag_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out);

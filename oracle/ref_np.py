@@ -216,6 +216,69 @@ def morph_gradient_u8(u8: np.ndarray, k: int) -> np.ndarray:
     return di - er
 
 
+def morph_u8(u8: np.ndarray, k: int, op: str) -> np.ndarray:
+    """cv2.erode / cv2.dilate / cv2.morphologyEx(MORPH_OPEN | MORPH_CLOSE) with ones(k,k) — indices.py:421-431.
+    Default border: out-of-image taps never win; opening = dilate(erode(x)), closing = erode(dilate(x))."""
+    r = k // 2
+    H, W = u8.shape
+
+    def erode(x):
+        p = np.pad(x, r, mode="constant", constant_values=255)
+        o = np.full((H, W), 255, np.uint8)
+        for dy in range(k):
+            for dx in range(k):
+                o = np.minimum(o, p[dy:dy + H, dx:dx + W])
+        return o
+
+    def dilate(x):
+        p = np.pad(x, r, mode="constant", constant_values=0)
+        o = np.zeros((H, W), np.uint8)
+        for dy in range(k):
+            for dx in range(k):
+                o = np.maximum(o, p[dy:dy + H, dx:dx + W])
+        return o
+
+    if op == "erosion":
+        return erode(u8)
+    if op == "dilation":
+        return dilate(u8)
+    if op == "opening":
+        return dilate(erode(u8))
+    if op == "closing":
+        return erode(dilate(u8))
+    if op == "gradient":
+        return morph_gradient_u8(u8, k)
+    raise ValueError(op)
+
+
+def calculate_morphological_features(band: np.ndarray) -> dict:
+    """indices.py:401-442: 15 float64 members."""
+    u8 = to_u8(robust_normalize(band))
+    return {f"{name}_{k}": morph_u8(u8, k, name) / 255.0 for k in (3, 5, 7)
+            for name in ("erosion", "dilation", "opening", "closing", "gradient")}
+
+
+def variance_feature(band: np.ndarray, scale: int) -> np.ndarray:
+    """calculate_multi_scale_features -> 'variance_scale_k' (indices.py:541-544)."""
+    b = robust_normalize(band)
+    mean = box_mean(b, scale, "reflect101")
+    mean_sq = box_mean(b * b, scale, "reflect101")
+    var = mean_sq - mean * mean
+    var[var < 0] = 0
+    return var
+
+
+def laplacian_feature(band: np.ndarray) -> np.ndarray:
+    """calculate_filter_responses -> 'laplacian' (indices.py:472-474): cv2.Laplacian(u8, CV_32F) (aperture 1: the cross
+    stencil [0 1 0; 1 -4 1; 0 1 0], BORDER_REFLECT_101) / 255.0, min-max normalised, float32 throughout."""
+    u8 = to_u8(robust_normalize(band)).astype(np.int32)
+    p = np.pad(u8, 1, mode="reflect")
+    lap = (p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4 * u8).astype(np.float32) / np.float32(255.0)
+    mn, mx = lap.min(), lap.max()
+    den = np.float32(np.float32(mx - mn) + np.float32(1e-10))
+    return ((lap - mn) / den).astype(np.float32)
+
+
 def gradient_feature(band: np.ndarray, k: int = 5) -> np.ndarray:
     """calculate_morphological_features -> 'gradient_5' (indices.py:411-415, 433, 440): float64."""
     b = robust_normalize(band)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k6_box(const float *__restrict__ x, int H
     out[(size_t)py * W + px] = (float)(acc * (1.0 / (double)(K * K)));
 }
 
-template <int K>
+template <int K, bool VAR>
 __global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int H, int W, float *__restrict__ out)
 {
     const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int H
     const float mm = mean * mean;
     float var = mean_sq - mm;
     if (var < 0.f) var = 0.f;
-    out[(size_t)py * W + px] = sqrtf(var);
+    out[(size_t)py * W + px] = VAR ? var : sqrtf(var);
 }
 
 template <int K>
@@ -102,6 +102,63 @@ __global__ __launch_bounds__(256) void k7_morph_grad(const uint8_t *__restrict__
         }
     }
     out[(size_t)py * W + px] = (uint8_t)(mx - mn);
+}
+
+// erode (MODE 0: min) / dilate (MODE 1: max) with a K x K rectangle; taps outside the image never win
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, int H, int W, uint8_t *__restrict__ out)
+{
+    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    constexpr int R = K / 2;
+    int acc = MODE == 0 ? 255 : 0;
+#pragma unroll
+    for (int dy = -R; dy <= R; dy++) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            const int xx = px + dx;
+            if (xx < 0 || xx >= W) continue;
+            const int v = q[(size_t)yy * W + xx];
+            acc = MODE == 0 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+        }
+    }
+    out[(size_t)py * W + px] = (uint8_t)acc;
+}
+
+// cv2.Laplacian(u8, CV_32F), aperture 1: cross stencil, BORDER_REFLECT_101; value / 255 in float32.
+// blockmin/blockmax[blk] = extrema over the block (for the min-max normalisation that follows)
+__global__ __launch_bounds__(256) void k8_laplace(const uint8_t *__restrict__ q, int H, int W, float *__restrict__ out,
+                                                  float *__restrict__ blockmin, float *__restrict__ blockmax)
+{
+    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
+    float l = 0.f;
+    const bool live = px < W && py < H;
+    if (live) {
+        const int xm = border_idx(px - 1, W, 1), xp = border_idx(px + 1, W, 1);
+        const int ym = border_idx(py - 1, H, 1), yp = border_idx(py + 1, H, 1);
+        const int c = q[(size_t)py * W + px];
+        const int s = (int)q[(size_t)ym * W + px] + (int)q[(size_t)yp * W + px] + (int)q[(size_t)py * W + xm] + (int)q[(size_t)py * W + xp] - 4 * c;
+        l = (float)s / 255.0f;
+        out[(size_t)py * W + px] = l;
+    }
+    float mn = wave_min(live ? l : INFINITY), mx = wave_max(live ? l : -INFINITY);
+    __shared__ float smn[4], smx[4];
+    if (lane_id() == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blockmin[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        blockmax[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void k8_sub_div(float *__restrict__ x, int64_t n, float sub, float den)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = x[i] - sub;
+        x[i] = d / den;
+    }
 }
 
 // Sobel magnitude; blockmax[blk] = max over the block
@@ -196,9 +253,9 @@ extern "C" int rsseg_local_std_f32(rsseg_ctx *ctx, const float *d_x, int H, int 
     {
         prof_scope ps(ctx, "box");
         switch (k) {
-        case 3: hipLaunchKernelGGL(k6_std<3>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 5: hipLaunchKernelGGL(k6_std<5>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 7: hipLaunchKernelGGL(k6_std<7>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        case 3: hipLaunchKernelGGL((k6_std<3, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        case 5: hipLaunchKernelGGL((k6_std<5, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        case 7: hipLaunchKernelGGL((k6_std<7, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
         default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "local_std: kernel size %d not in {3,5,7}", k);
         }
     }
@@ -219,6 +276,95 @@ extern "C" int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H
         case 7: hipLaunchKernelGGL(k7_morph_grad<7>, grid2d(H, W), dim3(256), 0, ctx->stream, d_q, H, W, d_out); break;
         default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph_gradient: kernel size %d not in {3,5,7}", k);
         }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_out || H < 1 || W < 1 || d_x == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "local_var: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "box");
+        switch (k) {
+        case 3: hipLaunchKernelGGL((k6_std<3, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        case 5: hipLaunchKernelGGL((k6_std<5, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        case 7: hipLaunchKernelGGL((k6_std<7, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
+        default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "local_var: kernel size %d not in {3,5,7}", k);
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+template <int MODE> static int morph_launch(rsseg_ctx *ctx, const uint8_t *in, int H, int W, int k, uint8_t *out)
+{
+    prof_scope ps(ctx, "stencil");
+    switch (k) {
+    case 3: hipLaunchKernelGGL((k7_morph<3, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
+    case 5: hipLaunchKernelGGL((k7_morph<5, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
+    case 7: hipLaunchKernelGGL((k7_morph<7, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
+    default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph: kernel size %d not in {3,5,7}", k);
+    }
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_morph_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_q || !d_out || H < 1 || W < 1 || d_q == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "morph: bad arguments");
+    if (op == RSSEG_MORPH_GRADIENT) return rsseg_morph_gradient_u8(ctx, d_q, H, W, k, d_out);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (op == RSSEG_MORPH_ERODE) RSCHK(morph_launch<0>(ctx, d_q, H, W, k, d_out));
+    else if (op == RSSEG_MORPH_DILATE) RSCHK(morph_launch<1>(ctx, d_q, H, W, k, d_out));
+    else if (op == RSSEG_MORPH_OPEN || op == RSSEG_MORPH_CLOSE) {
+        RSCHK(ws_reserve(ctx, (size_t)H * W));
+        uint8_t *tmp = (uint8_t *)ctx->d_ws;
+        if (op == RSSEG_MORPH_OPEN) {
+            RSCHK(morph_launch<0>(ctx, d_q, H, W, k, tmp));
+            RSCHK(morph_launch<1>(ctx, tmp, H, W, k, d_out));
+        } else {
+            RSCHK(morph_launch<1>(ctx, d_q, H, W, k, tmp));
+            RSCHK(morph_launch<0>(ctx, tmp, H, W, k, d_out));
+        }
+    } else
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "morph: unknown operation %d", op);
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_laplacian_norm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_q || !d_out || H < 1 || W < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "laplacian: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const dim3 g = grid2d(H, W);
+    const size_t nb = (size_t)g.x * g.y;
+    RSCHK(ws_reserve(ctx, 2 * nb * sizeof(float)));
+    RSCHK(pin_reserve(ctx, 2 * nb * sizeof(float)));
+    {
+        prof_scope ps(ctx, "stencil");
+        hipLaunchKernelGGL(k8_laplace, g, dim3(256), 0, ctx->stream, d_q, H, W, d_out, (float *)ctx->d_ws, (float *)ctx->d_ws + nb);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_ws, 2 * nb * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float mn = INFINITY, mx = -INFINITY;
+    for (size_t i = 0; i < nb; i++) {
+        mn = std::min(mn, ((const float *)ctx->h_pin)[i]);
+        mx = std::max(mx, ((const float *)ctx->h_pin)[nb + i]);
+    }
+    double mm[2] = {-(double)mn, (double)mx};  // MAX-reduce of the negated minimum
+    RSCHK(comm_allreduce_host(ctx, mm, 2, RSSEG_F64, RSSEG_MAX));
+    volatile float fmn = (float)(-mm[0]), fmx = (float)mm[1];
+    volatile float range = fmx - fmn;
+    volatile float den = range + 1e-10f;  // float32 throughout (NumPy 2 weak-scalar promotion)
+    {
+        prof_scope ps(ctx, "stencil");
+        hipLaunchKernelGGL(k8_sub_div, dim3((unsigned)std::min<int64_t>(2048, ceil_div64((int64_t)H * W, 256))), dim3(256), 0, ctx->stream,
+                           d_out, (int64_t)H * W, (float)fmn, (float)den);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

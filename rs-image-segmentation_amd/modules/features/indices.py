@@ -140,36 +140,42 @@ def calculate_glcm_features(band, distances=[1], angles=[0, np.pi / 4, np.pi / 2
 
 
 def calculate_morphological_features(band):
-    """reference indices.py:401-442 — the gradient members (the stack consumes 'gradient_5'); float64."""
+    """reference indices.py:401-442 — erosion / dilation / opening / closing / gradient at 3, 5, 7 (float64, u8 / 255.0;
+    the stack consumes 'gradient_5')."""
     d, (h, w) = _dev(band)
     ctx = _ctx()
     q = ctx.quantize_u8(_P.renormalize(ctx, d), 255.0)
-    return {f"gradient_{k}": _host(ctx.morph_gradient(q, h, w, k), (h, w)) / 255.0 for k in (3, 5, 7)}
+    ops = (("erosion", _L.MORPH_ERODE), ("dilation", _L.MORPH_DILATE), ("opening", _L.MORPH_OPEN), ("closing", _L.MORPH_CLOSE),
+           ("gradient", _L.MORPH_GRADIENT))
+    return {f"{name}_{k}": _host(ctx.morph(q, h, w, k, op), (h, w)) / 255.0 for k in (3, 5, 7) for name, op in ops}
 
 
 def calculate_multi_scale_features(band, scales=[1, 3, 5, 7]):
-    """reference indices.py:519-562 — mean_scale_k and std_dev_scale_k (the stack consumes
-    'std_dev_scale_5'); variance / entropy members are not produced."""
+    """reference indices.py:519-562 — mean_scale_k, variance_scale_k and std_dev_scale_k (the stack consumes
+    'std_dev_scale_5'); the rank-filter entropy members (scikit-image) are not produced."""
     d, (h, w) = _dev(band)
     ctx = _ctx()
     n = _P.renormalize(ctx, d)
     out = {}
     for k in scales:
-        if k == 1:
+        if k == 1:  # a 1x1 blur is the identity: variance = x*x - x*x = 0
             out["mean_scale_1"] = _host(n, (h, w))
+            out["variance_scale_1"] = np.zeros((h, w), np.float32)
             out["std_dev_scale_1"] = np.zeros((h, w), np.float32)
             continue
         out[f"mean_scale_{k}"] = _host(ctx.box_mean(n, h, w, k, _L.BORDER_REFLECT101), (h, w))
+        out[f"variance_scale_{k}"] = _host(ctx.local_var(n, h, w, k), (h, w))
         out[f"std_dev_scale_{k}"] = _host(ctx.local_std(n, h, w, k), (h, w))
     return out
 
 
 def calculate_filter_responses(band):
-    """reference indices.py:444-482 — 'sobel_mag' (the member the stack consumes)."""
+    """reference indices.py:444-482 — 'laplacian' and 'sobel_mag' (the member the stack consumes); the Gaussian /
+    DoG members (cv2's fixed-point uint8 GaussianBlur) are not produced."""
     d, (h, w) = _dev(band)
     ctx = _ctx()
     q = ctx.quantize_u8(_P.renormalize(ctx, d), 255.0)
-    return {"sobel_mag": _host(ctx.sobel_mag(q, h, w), (h, w))}
+    return {"laplacian": _host(ctx.laplacian_norm(q, h, w), (h, w)), "sobel_mag": _host(ctx.sobel_mag(q, h, w), (h, w))}
 
 
 def add_spatial_context(features_array, window_size=7):

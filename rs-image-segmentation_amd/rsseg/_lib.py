@@ -16,6 +16,7 @@ MAX_RANKS = 16
 F32, F64, I64 = 0, 1, 2
 SUM, MIN, MAX = 0, 1, 2
 BORDER_REFLECT, BORDER_REFLECT101 = 0, 1
+MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int)
 
@@ -65,6 +66,9 @@ SIGNATURES = {
     "rsseg_box_mean_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "rsseg_local_std_f32": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "rsseg_morph_gradient_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_morph_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "rsseg_local_var_f32": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_laplacian_norm_u8": (_int, [_vp, _vp, _int, _int, _vp]),
     "rsseg_sobel_mag_u8": (_int, [_vp, _vp, _int, _int, _vp]),
     "rsseg_kmeans_fit_predict": (_int, [_vp, _PP, _int, _int, _i64, _int, C.c_uint32, _int, C.c_double, _vp,
                                         C.POINTER(C.c_double), C.POINTER(KMeansInfo)]),

@@ -133,7 +133,7 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
     std5 = ctx.local_std(nir2, H, W, 5)
     sob = ctx.sobel_mag(q255, H, W)
     planes = level1 + ctx_planes + [glcm["contrast"], glcm["homogeneity"], grad, std5, sob]
-    extras = dict(indices=idx, norm=norm_all, pca=pcs, pca_ratio=ratio, pca_model=model, glcm=glcm, lohi=lohi)
+    extras = dict(indices=idx, norm=norm_all, pca=pcs, pca_ratio=ratio, pca_model=model, glcm=glcm, lohi=lohi, nir2=nir2, q255=q255)
     return planes, extras
 
 

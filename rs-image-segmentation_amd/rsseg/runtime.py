@@ -263,6 +263,25 @@ class Context:
         self._chk(self.lib.rsseg_morph_gradient_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
         return out
 
+    def morph(self, q, H: int, W: int, k: int, op: int):
+        """op: L.MORPH_ERODE / DILATE / OPEN / CLOSE / GRADIENT on a uint8 plane; uint8 result."""
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_morph_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, op, C.c_void_p(out.data_ptr())))
+        return out
+
+    def local_var(self, plane, H: int, W: int, k: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.float32)
+        self._chk(self.lib.rsseg_local_var_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
+        return out
+
+    def laplacian_norm(self, q, H: int, W: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.float32)
+        self._chk(self.lib.rsseg_laplacian_norm_u8(self.h, C.c_void_p(q.data_ptr()), H, W, C.c_void_p(out.data_ptr())))
+        return out
+
     def sobel_mag(self, q, H: int, W: int):
         torch = _torch()
         out = self.empty(H * W, torch.float32)

@@ -40,9 +40,21 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     fd["pca_result"] = [host(p) for p in ex["pca"]]
     fd["variance_ratio"] = ex["pca_ratio"]
     fd["glcm_features"] = {k: host(v) for k, v in ex["glcm"].items()}
-    fd["morphological_features"] = {"gradient_5": host(planes[16]) / 255.0}
-    fd["multi_scale_features"] = {"std_dev_scale_5": host(planes[17])}
-    fd["filter_features"] = {"sobel_mag": host(planes[18])}
+    # the window-operator members of the dict (indices.py:401-482, 519-562) beyond the three the stack consumes;
+    # not produced: LBP, rank-filter entropy (scikit-image), Gaussian / DoG (cv2 fixed-point GaussianBlur)
+    from . import _lib as L
+    nir2, q255 = ex["nir2"], ex["q255"]  # the re-normalised NIR band and its uint8 image (indices.py:412-415)
+    ops = (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE),
+           ("gradient", L.MORPH_GRADIENT))
+    fd["morphological_features"] = {f"{name}_{k}": ctx.morph(q255, h, w, k, op).cpu().numpy().reshape(h, w) / 255.0
+                                    for k in (3, 5, 7) for name, op in ops}
+    ms = {"mean_scale_1": host(nir2), "variance_scale_1": np.zeros((h, w), np.float32), "std_dev_scale_1": np.zeros((h, w), np.float32)}
+    for k in (3, 5, 7):
+        ms[f"mean_scale_{k}"] = host(ctx.box_mean(nir2, h, w, k, L.BORDER_REFLECT101))
+        ms[f"variance_scale_{k}"] = host(ctx.local_var(nir2, h, w, k))
+        ms[f"std_dev_scale_{k}"] = host(planes[17]) if k == 5 else host(ctx.local_std(nir2, h, w, k))
+    fd["multi_scale_features"] = ms
+    fd["filter_features"] = {"laplacian": host(ctx.laplacian_norm(q255, h, w)), "sobel_mag": host(planes[18])}
     stack = P.stack19_to_host(planes, h, w)
     hier = {"level_1": np.ascontiguousarray(stack[:, :, :14]), "level_2": np.ascontiguousarray(stack[:, :, 14:]), "all": stack}
     return fd, hier

@@ -38,6 +38,26 @@ def test_indices_module_matches_reference_functions(ctx, crop):
         I.calculate_evi(n, r, b, L=2)
 
 
+def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
+    """calculate_morphological_features / calculate_multi_scale_features / calculate_filter_responses of the mirror:
+    member names, dtypes and values of the members that are produced (reference indices.py:401-482, 519-562)."""
+    from modules.features import indices as I
+    nir = crop["norm"][3]
+    mf = I.calculate_morphological_features(nir)
+    want = oracle.calculate_morphological_features(nir)
+    assert sorted(mf) == sorted(want) and len(mf) == 15
+    for k in want:
+        assert mf[k].dtype == np.float64 and np.array_equal(mf[k], want[k]), k
+    ms = I.calculate_multi_scale_features(nir)
+    assert {f"{m}_scale_{k}" for m in ("mean", "variance", "std_dev") for k in (1, 3, 5, 7)} == set(ms)
+    assert np.array_equal(ms["std_dev_scale_5"], oracle.std_dev_feature(nir, 5))
+    assert np.array_equal(ms["variance_scale_3"], oracle.variance_feature(nir, 3))
+    assert not ms["variance_scale_1"].any() and ms["variance_scale_1"].dtype == np.float32
+    fr = I.calculate_filter_responses(nir)
+    assert np.array_equal(fr["sobel_mag"], oracle.sobel_mag_feature(nir))
+    assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(nir)) and fr["laplacian"].dtype == np.float32
+
+
 def test_stage_function_layout_and_files(ctx, crop, tmp_path, oracle):
     from rsseg import stages
     fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
@@ -48,6 +68,12 @@ def test_stage_function_layout_and_files(ctx, crop, tmp_path, oracle):
     for c in range(19):
         tol = 2e-4 if c in (6, 13) else 1e-5
         assert np.allclose(hier["all"][:, :, c], want["all"][:, :, c], rtol=0, atol=tol), c
+    # the dict members around the stack (indices.py:401-482, 519-562)
+    assert len(fd["morphological_features"]) == 15 and len(fd["multi_scale_features"]) == 12
+    assert np.array_equal(fd["morphological_features"]["gradient_5"], hier["all"][:, :, 16])
+    assert np.array_equal(fd["multi_scale_features"]["std_dev_scale_5"].astype(np.float64), hier["all"][:, :, 17])
+    assert np.array_equal(fd["morphological_features"]["closing_7"], oracle.calculate_morphological_features(crop["norm"][3])["closing_7"])
+    assert set(fd["filter_features"]) == {"laplacian", "sobel_mag"}
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
     assert np.array_equal(np.load(paths["all"]), hier["all"])
     import pickle

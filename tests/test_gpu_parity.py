@@ -250,6 +250,33 @@ def test_window_ops_bitexact_vs_oracle(ctx, oracle):
     assert np.array_equal(host(ctx.box_mean(dev(ctx, t), 2, 3, 3, L.BORDER_REFLECT), (2, 3)), oracle.box_mean(t, 3, "reflect"))
 
 
+def test_morphology_variance_laplacian_bitexact_vs_oracle(ctx, oracle):
+    """The remaining uint8 / float32 window members of the feature dict (erosion, dilation, opening, closing at 3/5/7,
+    variance_scale_k, laplacian) against the oracle, bit for bit, on an odd-sized plane."""
+    from rsseg import _lib as L
+    rng = np.random.default_rng(21)
+    H, W = 67, 201
+    u8 = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    u8[20:40, 50:90] = 17
+    ops = (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE),
+           ("gradient", L.MORPH_GRADIENT))
+    for k in (3, 5, 7):
+        for name, op in ops:
+            assert np.array_equal(host(ctx.morph(dev(ctx, u8), H, W, k, op), (H, W)), oracle.morph_u8(u8, k, name)), (name, k)
+    x = rng.random((H, W)).astype(np.float32)
+    for k in (3, 5, 7):
+        mean = oracle.box_mean(x, k, "reflect101")
+        var = oracle.box_mean(x * x, k, "reflect101") - mean * mean
+        var[var < 0] = 0
+        assert np.array_equal(host(ctx.local_var(dev(ctx, x), H, W, k), (H, W)), var), k
+    xn = oracle.robust_normalize(x)
+    q = (oracle.robust_normalize(xn) * 255).astype(np.uint8)
+    got = host(ctx.laplacian_norm(dev(ctx, q), H, W), (H, W))
+    assert np.array_equal(got, oracle.laplacian_feature(xn)), np.abs(got - oracle.laplacian_feature(xn)).max()
+    with pytest.raises(Exception):
+        ctx.morph(dev(ctx, u8), H, W, 4, L.MORPH_ERODE)
+
+
 def test_stack19_and_class_map_end_to_end(ctx, scene, oracle, golden_dir):
     """Bundled scene -> 19-feature stack on the GPU -> bundled forest on the GPU == the reference's
     committed class_map.npy; the stack equals the oracle's (float columns within 1e-5)."""

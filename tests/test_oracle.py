@@ -145,6 +145,34 @@ def test_class_map_end_to_end(oracle, scene, golden_dir):
         assert scene["roi_mask"][y, x] == lab
 
 
+def test_morphology_and_laplacian_restatements_vs_scipy(oracle):
+    """cv2 is absent here, so the uint8 window operators of calculate_morphological_features / calculate_filter_responses
+    are pinned against an independent implementation: scipy.ndimage with the equivalent border rules
+    (constant border that never wins for erode / dilate; mode='mirror' = BORDER_REFLECT_101 for the Laplacian)."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (41, 57)).astype(np.uint8)
+    u8[5:15, 5:15] = 200
+    for k in (3, 5, 7):
+        er = ndi.minimum_filter(u8, size=k, mode="constant", cval=255)
+        di = ndi.maximum_filter(u8, size=k, mode="constant", cval=0)
+        assert np.array_equal(oracle.morph_u8(u8, k, "erosion"), er)
+        assert np.array_equal(oracle.morph_u8(u8, k, "dilation"), di)
+        assert np.array_equal(oracle.morph_u8(u8, k, "opening"), ndi.maximum_filter(er, size=k, mode="constant", cval=0))
+        assert np.array_equal(oracle.morph_u8(u8, k, "closing"), ndi.minimum_filter(di, size=k, mode="constant", cval=255))
+        assert np.array_equal(oracle.morph_u8(u8, k, "gradient"), di - er)
+    band = rng.random((41, 57)).astype(np.float32)
+    q = oracle.to_u8(oracle.robust_normalize(band)).astype(np.float32)
+    lap = ndi.correlate(q, np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float32), mode="mirror") / np.float32(255.0)
+    want = (lap - lap.min()) / (lap.max() - lap.min() + 1e-10)
+    got = oracle.laplacian_feature(band)
+    assert got.dtype == np.float32 and want.dtype == np.float32
+    assert np.array_equal(got, want)
+    feats = oracle.calculate_morphological_features(band)
+    assert len(feats) == 15 and all(v.dtype == np.float64 for v in feats.values())
+    assert np.all(feats["opening_5"] <= feats["closing_5"])
+
+
 def test_pin_report_is_committed(golden_dir):
     rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))
     assert rep["class_map_agreement"] >= 0.999
