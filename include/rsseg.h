@@ -59,8 +59,10 @@ typedef struct rsseg_ctx rsseg_ctx;
 typedef int (*rsseg_allreduce_fn)(void *user, int64_t offset, int64_t count, int dtype, int op);
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
- * for a stream owned by the context. */
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL for a non-blocking
+ * stream owned by the context.  The library orders its work on THAT stream only: an input plane still being written
+ * by work on another stream must be complete before the call.  A host whose producers run on the legacy default
+ * stream (torch's default) passes hipStreamLegacy ((hipStream_t)1), as rsseg/runtime.py does. */
 int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out);
 void rsseg_ctx_destroy(rsseg_ctx *ctx);
 const char *rsseg_last_error(const rsseg_ctx *ctx);

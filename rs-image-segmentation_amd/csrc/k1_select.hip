@@ -178,12 +178,22 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));    \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
         SEL_ATTR(256) SEL_ATTR(1024)
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
         attr_done = true;
     }
     const int threads = sel_threads;
     int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
     auto launch = [&](int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb) {
-#define SEL_GO(P, TH) hipLaunchKernelGGL((k1_hist<P, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan)
+#define SEL_GO(P, TH)                                                                                                             \
+    do {                                                                                                                          \
+        if (getenv("RSSEG_SEL_UNR1")) hipLaunchKernelGGL((k1_hist<P, TH, 1>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan); \
+        else hipLaunchKernelGGL((k1_hist<P, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan);  \
+    } while (0)
 #define SEL_PASS(TH)                         \
     do {                                     \
         if (pass == 0) SEL_GO(0, TH);        \

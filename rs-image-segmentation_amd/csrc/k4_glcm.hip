@@ -159,31 +159,12 @@ __device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)));
 }
-__device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) * __builtin_bit_cast(us2, b)));
-}
-template <int N> __device__ __forceinline__ unsigned pk_shr(unsigned a)
-{
-    return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) >> (us2)(N)));
-}
 
-// window rows packed 4 pixels per register: w[r][0] = px 0..3, w[r][1] = px 4..7 (zero beyond WIN-1)
-template <int R, int C> __device__ __forceinline__ int px_at(const unsigned (&w)[8][2])
-{
-    return (int)((w[R][C >> 2] >> (8 * (C & 3))) & 0xffu);
-}
 
 __device__ __forceinline__ void pin32(unsigned &v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(v));
-#endif
-}
-__device__ __forceinline__ void pin_pair(unsigned &a, unsigned &b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(a), "+v"(b));
 #endif
 }
 __device__ __forceinline__ void pin64(long long &v)
@@ -193,13 +174,6 @@ __device__ __forceinline__ void pin64(long long &v)
 #endif
 }
 
-// 13-bit unordered pair key: diag << 12 | lo << 6 | hi   (levels <= 64)
-__device__ __forceinline__ unsigned pair_key(int x, int y, unsigned &d)
-{
-    const int lo = x < y ? x : y, hi = x < y ? y : x;
-    d = (unsigned)(hi - lo);
-    return ((unsigned)lo << 6) | (unsigned)hi | (d == 0 ? 4096u : 0u);
-}
 
 // pair moments of one angle from whole packed rows: S1 = sum|a-b|, XY = sum ab, M2 = sum a^2+b^2, M1 = sum a+b
 template <int WIN, int DR, int DC>

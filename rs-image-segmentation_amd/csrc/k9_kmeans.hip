@@ -135,32 +135,23 @@ __global__ __launch_bounds__(KM_THREADS) void km_minmax(planes_t pl, int64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass B/C: exact sums.  MODE 0: sum fixed(xs).  MODE 1: sum fixed(fl((xs-m)*(xs-m))).
+// mean pass: exact sums of fixed(xs) (the np.var numerators ride on the first k-means++ pass, km_kpp MODE 0).
 // grid (nblk, F); partial[f][blk] int64
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE>
+template <typename T>
 __global__ __launch_bounds__(KM_THREADS) void km_moment(planes_t pl, int64_t n, const scaler_t<T> *__restrict__ sp,
                                                         long long *__restrict__ partial)
 {
     constexpr int PXL = vt<T>::PXL;
     const int f = blockIdx.y;
-    const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+    const T sc = sp->scale[f], mnv = sp->minv[f];
     long long acc = 0;
     for (int64_t base = ((int64_t)blockIdx.x * KM_THREADS + threadIdx.x) * PXL; base < n; base += (int64_t)gridDim.x * KM_THREADS * PXL) {
         T v[PXL];
         load_px<T>(pl.p[f], base, n, v);
 #pragma unroll
         for (int i = 0; i < PXL; i++)
-            if (base + i < n) {
-                T xs = scaled<T>(v[i], sc, mnv);
-                if (MODE == 0) {
-                    acc += to_fixed40((double)xs);
-                } else {
-                    T d = xs - me;
-                    T dd = d * d;
-                    acc += to_fixed40((double)dd);
-                }
-            }
+            if (base + i < n) acc += to_fixed40((double)scaled<T>(v[i], sc, mnv));
     }
     acc = wave_sum(acc);
     __shared__ long long sacc[4];
@@ -962,10 +953,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
 
     // ---- X.mean(axis=0) and np.var(X, axis=0) with exact sums ----
     const T Nt = (T)N;
-    auto moment_pass = [&](int mode, i128 *sums) -> int {
+    auto mean_pass = [&](i128 *sums) -> int {
         if (n > 0) {
-            if (mode == 0) hipLaunchKernelGGL((km_moment<T, 0>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
-            else hipLaunchKernelGGL((km_moment<T, 1>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            hipLaunchKernelGGL((km_moment<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, sizeof(long long) * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
@@ -984,7 +974,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         return RSSEG_OK;
     };
     i128 sums[RSSEG_MAX_FEATURES];
-    RSCHK(moment_pass(0, sums));
+    RSCHK(mean_pass(sums));
     for (int f = 0; f < F; f++) {
         volatile T s = fixed_to_T<T>(sums[f]);
         volatile T m = s / Nt;

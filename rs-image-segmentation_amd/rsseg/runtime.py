@@ -62,7 +62,11 @@ class Context:
         torch.cuda.set_device(self.device)
         h = C.c_void_p()
         self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self.lib.rsseg_ctx_create(device, C.c_void_p(self.torch_stream.cuda_stream), C.byref(h))
+        # torch's default stream is the legacy null stream (handle 0).  NULL would make the library create a private
+        # non-blocking stream that does NOT order after torch kernels still writing an input plane, so the legacy
+        # default stream is named explicitly (hipStreamLegacy == (hipStream_t)1).
+        handle = self.torch_stream.cuda_stream or 1
+        rc = self.lib.rsseg_ctx_create(device, C.c_void_p(handle), C.byref(h))
         if rc != 0:
             raise RssegError(f"rsseg_ctx_create failed ({rc}): {self.lib.rsseg_last_error(None).decode()}")
         self.h = h

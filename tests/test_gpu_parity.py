@@ -518,3 +518,119 @@ def test_kmeans_many_clusters_and_features(ctx, oracle, k, F, dt):
     assert np.array_equal(meta["init_indices"], info["init_indices"])
     assert meta["n_iter"] == info["n_iter"]
     assert np.array_equal(host(labels), want)
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def _pattern_np(y0, y1, x0, x1, b):
+    """Integer-valued synthetic DN in [0, 250]: blocks of 64 x 64 with a per-band level plus a hash texture."""
+    y = np.arange(y0, y1, dtype=np.int64)[:, None]
+    x = np.arange(x0, x1, dtype=np.int64)[None, :]
+    base = (((y // 64) * 7 + (x // 64) * 3 + b * 5) % 8) * 24 + 20
+    tex = ((y * 131 + x * 71 + b * 37) ^ ((y >> 3) * (x >> 2) + b)) % 23
+    return (base + tex).astype(np.float32)
+
+
+def _pattern_gpu(torch, device, H, W, b):
+    out = torch.empty(H * W, dtype=torch.float32, device=device)
+    x = torch.arange(W, device=device, dtype=torch.int64)[None, :]
+    for y0 in range(0, H, 1024):
+        y1 = min(H, y0 + 1024)
+        y = torch.arange(y0, y1, device=device, dtype=torch.int64)[:, None]
+        base = (((y // 64) * 7 + (x // 64) * 3 + b * 5) % 8) * 24 + 20
+        tex = ((y * 131 + x * 71 + b * 37) ^ ((y >> 3) * (x >> 2) + b)) % 23
+        out[y0 * W:y1 * W] = (base + tex).to(torch.float32).reshape(-1)
+    return out
+
+
+def test_full_size_16384_properties(ctx, oracle):
+    """BASELINE's full size (16384 x 16384 x 7, 268 Mpx): far beyond the CPU oracle, so
+      * order statistics against a device sort (exact),
+      * the LOCAL stages (normalise + indices, quantise + GLCM small maps) against the oracle on a crop taken at the
+        FAR corner of the raster, where any 32-bit index overflow would show (bit-exact; the global percentiles are
+        handed to the oracle),
+      * the row-striped upsample against the whole-plane upsample on the last rows (same values),
+      * config 3 end to end: deterministic, every cluster centre is the float64 mean of its members' scaled features to
+        1e-6, sampled labels are arg-min labels."""
+    import torch
+    from rsseg import pipeline as P
+    H = W = 16384
+    n = H * W
+    bands = [_pattern_gpu(torch, ctx.device, H, W, b) for b in range(7)]
+    # -- order statistics
+    ranks = [int(0.02 * (n - 1)), int(0.02 * (n - 1)) + 1, n // 2, int(0.98 * (n - 1)), n - 1, 0]
+    got, nn = ctx.order_stats(bands[3], ranks)
+    assert nn == 0
+    srt = torch.sort(bands[3]).values
+    for r, g in zip(ranks, got):
+        assert float(srt[r]) == float(g), r
+    del srt
+    # -- local stages at the far corner
+    lohi = P.band_lohi(ctx, bands)
+    idx, norms = P.spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+    ch, cw = 48, 80
+    y0, x0 = H - ch, W - cw
+
+    def crop(t):
+        return t.reshape(H, W)[y0:, x0:].cpu().numpy()
+
+    cb = [_pattern_np(y0, H, x0, W, b) for b in range(5)]
+    for b in range(5):
+        assert np.array_equal(crop(bands[b]), cb[b])
+    cn = []
+    for b in range(5):
+        lo, hi = lohi[b]
+        c = np.minimum(np.maximum(cb[b], lo), hi)
+        cn.append(((c - lo) / (hi - lo + np.float32(1e-10))).astype(np.float32))
+        assert np.array_equal(crop(norms[b]), cn[b]), b
+    bl, g, r, nir, s = cn
+    want = {"ndvi": oracle.calculate_ndvi(nir, r), "evi": oracle.calculate_evi(nir, r, bl), "msavi": oracle.calculate_msavi(nir, r),
+            "ndwi": oracle.calculate_ndwi(g, nir), "mndwi": oracle.calculate_mndwi(g, s), "ndbi": oracle.calculate_ndbi(s, nir),
+            "bsi": oracle.calculate_bsi(bl, r, nir, s)}
+    for k, v in want.items():
+        assert np.array_equal(crop(idx[k]), v), k
+    nir2 = P.renormalize(ctx, norms[3])
+    q = ctx.quantize_u8(nir2, 31.0)
+    small, (oh, ow) = ctx.glcm(q, H, W, 32, 7, 1)
+    assert (oh, ow) == (H - 6, W - 6)
+    qc = q.reshape(H, W)[y0:, x0:].cpu().numpy()
+    wantg = oracle.glcm_small_maps(qc, 32, 7, 1, mode=1)
+    for gpl, k in zip(small, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
+        gc = gpl.reshape(oh, ow)[y0:, x0:].cpu().numpy()   # windows whose top-left corner lies in the crop
+        assert np.array_equal(gc, wantg[k]), k
+    # -- upsample: last 40 rows through the striped entry point == the same rows of the whole-plane call
+    up = ctx.resize_bilinear(small[0], oh, ow, H, W)
+    rows0 = H - 40
+    s0 = oh - 48
+    part = ctx.resize_bilinear_rows(small[0].reshape(oh, ow)[s0:].reshape(-1).contiguous(), oh - s0, ow, s0, oh, 40, W, rows0, H)
+    assert torch.equal(part, up.reshape(H, W)[rows0:].reshape(-1))
+    del up, part, idx, norms, nir2, q, small
+    torch.cuda.empty_cache()
+    # -- config 3 end to end
+    k = 8
+    labels, meta, planes = P.config3(ctx, bands, H, W, k, 7, 1, 3)
+    labels2, meta2, _ = P.config3(ctx, bands, H, W, k, 7, 1, 3)
+    assert torch.equal(labels, labels2) and meta["n_iter"] == meta2["n_iter"] and np.array_equal(meta["centers"], meta2["centers"])
+    assert int(labels.min()) == 0 and int(labels.max()) == k - 1
+    F = len(planes)
+    scale = torch.tensor(meta["scale"], dtype=torch.float64, device=ctx.device)
+    mn = torch.tensor(meta["min"], dtype=torch.float64, device=ctx.device)
+    cnt = torch.bincount(labels.to(torch.int64), minlength=k).to(torch.float64)
+    assert float(cnt.min()) > 0
+    lab64 = labels.to(torch.int64)
+    masks = [labels == j for j in range(k)]
+    for f in (0, 7, 11, 14):
+        # float32 steps of MinMaxScaler.transform as the library applies them, summed in float64
+        xs = (planes[f] * scale[f].to(torch.float32) + mn[f].to(torch.float32)).to(torch.float64)
+        zero = torch.zeros((), dtype=torch.float64, device=ctx.device)
+        sums = torch.stack([torch.where(masks[j], xs, zero).sum() for j in range(k)])
+        mean_f = (sums / cnt).cpu().numpy()
+        # the last M-step precedes the final E-step, so a few pixels may have moved since: tolerance, not equality
+        assert np.allclose(mean_f, meta["centers"][:, f], rtol=0, atol=1e-3), (f, np.abs(mean_f - meta["centers"][:, f]).max())
+        del xs
+    del masks
+    sub = torch.randint(0, n, (200000,), device=ctx.device, generator=torch.Generator(device=ctx.device).manual_seed(5))
+    Xs = torch.stack([(planes[f][sub] * scale[f].to(torch.float32) + mn[f].to(torch.float32)).to(torch.float64) for f in range(F)], 1)
+    C = torch.tensor(meta["centers"], dtype=torch.float64, device=ctx.device)
+    d = ((Xs[:, None, :] - C[None]) ** 2).sum(-1)
+    mine = d[torch.arange(sub.numel(), device=ctx.device), lab64[sub]]
+    assert float((mine - d.min(1).values).max()) <= 1e-5
