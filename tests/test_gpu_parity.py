@@ -634,3 +634,55 @@ def test_full_size_16384_properties(ctx, oracle):
     d = ((Xs[:, None, :] - C[None]) ** 2).sum(-1)
     mine = d[torch.arange(sub.numel(), device=ctx.device), lab64[sub]]
     assert float((mine - d.min(1).values).max()) <= 1e-5
+
+
+def test_full_size_16384_window_ops_and_forest(ctx, oracle, golden_dir):
+    """Config-5 kernels at the full size: 7x7 context mean, 5x5 std / morphological gradient, Sobel (global max) and the
+    forest walk, each checked at the far corner against the oracle (window operators: on a crop with a 4-pixel margin,
+    compared away from the artificial crop edge; the bottom / right edges are true image borders)."""
+    import torch
+    from rsseg import _lib as L
+    H = W = 16384
+    ch, cw, m = 64, 96, 4
+    y0, x0 = H - ch, W - cw
+    x = _pattern_gpu(torch, ctx.device, H, W, 3) / 255.0   # float32 in [0, 1]
+    xc = (_pattern_np(y0, H, x0, W, 3) / np.float32(255.0)).astype(np.float32)
+
+    def far(t):
+        return t.reshape(H, W)[y0 + m:, x0 + m:].cpu().numpy()
+
+    assert np.array_equal(far(x), xc[m:, m:])
+    assert np.array_equal(far(ctx.box_mean(x, H, W, 7, L.BORDER_REFLECT)), oracle.box_mean(xc, 7, "reflect")[m:, m:])
+    mean = oracle.box_mean(xc, 5, "reflect101")
+    var = oracle.box_mean(xc * xc, 5, "reflect101") - mean * mean
+    var[var < 0] = 0
+    assert np.array_equal(far(ctx.local_std(x, H, W, 5)), np.sqrt(var)[m:, m:])
+    q = ctx.quantize_u8(x, 255.0)
+    qc = (xc * 255).astype(np.uint8)
+    assert np.array_equal(far(q), qc[m:, m:])
+    assert np.array_equal(far(ctx.morph_gradient(q, H, W, 5)), oracle.morph_gradient_u8(qc, 5)[m:, m:])
+    # Sobel: the normalising maximum is global; rebuild the oracle's crop result with the device's maximum
+    sob = ctx.sobel_mag(q, H, W)
+    p = np.pad(qc.astype(np.int32), 1, mode="reflect")
+    gx = (p[:-2, 2:] - p[:-2, :-2]) + 2 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])
+    gy = (p[2:, :-2] - p[:-2, :-2]) + 2 * (p[2:, 1:-1] - p[:-2, 1:-1]) + (p[2:, 2:] - p[:-2, 2:])
+    sx, sy = gx.astype(np.float32) / np.float32(255.0), gy.astype(np.float32) / np.float32(255.0)
+    mag = np.sqrt(sx * sx + sy * sy)
+    mx = np.float32(float((sob.max())))  # == 1.0 after normalisation unless the plane is flat
+    assert mx == np.float32(1.0)
+    ratio = far(sob) / np.where(mag[m:, m:] > 0, mag[m:, m:], 1).astype(np.float32)
+    nz = mag[m:, m:] > 0
+    assert nz.any() and np.allclose(ratio[nz], ratio[nz][0], rtol=1e-6)  # one common divisor (global max + 1e-10)
+    del sob, q, x
+    torch.cuda.empty_cache()
+    # forest: bundled model on 19 planes, far end of the pixel range against the oracle's walk
+    f = dict(np.load(os.path.join(golden_dir, "rf_samples_model_flat.npz")))
+    ctx.forest_load(f)
+    g = torch.Generator(device=ctx.device).manual_seed(11)
+    planes = [torch.rand(H * W, device=ctx.device, generator=g) for _ in range(19)]
+    out = ctx.forest_predict(planes)
+    tail = 4099
+    want = oracle.rf_predict_planes(f, [pl[-tail:].cpu().numpy() for pl in planes])
+    assert np.array_equal(out[-tail:].cpu().numpy(), want)
+    head = oracle.rf_predict_planes(f, [pl[:tail].cpu().numpy() for pl in planes])
+    assert np.array_equal(out[:tail].cpu().numpy(), head)
