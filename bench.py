@@ -202,6 +202,7 @@ def main():
             ms, cnt = ms + ms2, cnt + cnt2
         if cnt:
             fams[fam] = (ms, cnt)
+    comm_ms, comm_cnt = ctx.prof_get("allreduce")
     ctx.prof_enable(False)
 
     if rank == 0:
@@ -238,7 +239,8 @@ def main():
                                        " + PCA + GLCM(21/21) + 7x7 context + morphology/std/Sobel -> 19-feature stack -> RandomForest(100 trees, max_depth 16) inference")),
                        "tile": [H, W, 7], "n_features": F, "n_clusters": k if args.config != "c5" else None,
                        "kmeans_n_iter": int(meta["n_iter"]) if meta else None,
-                       "parallelism": f"row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials"},
+                       "parallelism": f"row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials",
+                       "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

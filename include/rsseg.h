@@ -92,6 +92,12 @@ int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms, int64_t *
  * caller exactly as NumPy does (host arithmetic on two scalars). */
 int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, const int64_t *ranks,
                           int nranks, float *out_values, int64_t *n_nan_out);
+/* The same for up to 8 planes of equal length at once (ranks: [nplanes][nranks], out_values: [nplanes][nranks],
+ * n_nan_out: [nplanes]): the planes advance pass by pass together, so a group costs three host synchronisations
+ * and three all-reduces instead of three per plane.  With world > 1 the communication buffer must hold
+ * nplanes * 262 208 bytes. */
+int rsseg_order_stats_multi_f32(rsseg_ctx *ctx, const float *const *d_planes, int nplanes, int64_t n_local,
+                                const int64_t *ranks, int nranks, float *out_values, int64_t *n_nan_out);
 
 /* ---- K2: percentile normalisation + spectral indices ------------------------------------ */
 /* robust_normalize (indices.py:25-48), elementwise part: clip to [lo,hi], (x-lo)/(hi-lo+1e-10)

@@ -1,6 +1,8 @@
 // Context, workspace, communication hook and per-kernel timers of librsseg_hip.so.
 #include <stdarg.h>
 
+#include <chrono>
+
 #include "common.h"
 
 int rs_fail(rsseg_ctx *ctx, int code, const char *fmt, ...)
@@ -148,12 +150,18 @@ int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, in
     const size_t esz = dtype == RSSEG_F32 ? 4 : 8;
     const size_t bytes = esz * (size_t)count;
     if (bytes > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "comm buffer too small (%zu > %zu)", bytes, ctx->comm_bytes);
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
     if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
     HIPCHK(ctx, hipMemcpyAsync(host, ctx->d_comm, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_on) {  // host wall time of the whole exchange (staging copies + collective), name "allreduce"
+        prof_entry &e = ctx->prof["allreduce"];
+        e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        e.launches++;
+    }
     return RSSEG_OK;
 }
 

@@ -149,22 +149,22 @@ static float key_to_f32(uint32_t k)
     return f;
 }
 
-extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, const int64_t *ranks,
-                                     int nranks, float *out_values, int64_t *n_nan_out)
+// All planes advance pass by pass together: ONE device-to-host copy, ONE stream synchronisation and ONE all-reduce
+// per pass for the whole group (3 per group instead of 3 per plane).
+#define SEL_MAX_PLANES 8
+static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P, int64_t n_local, const int64_t *ranks, int nranks,
+                            float *out_values, int64_t *n_nan_out)
 {
-    if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_x || n_local < 0 || !ranks || !out_values || nranks < 1 || nranks > RSSEG_MAX_RANKS)
-        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: bad arguments (n=%lld nranks=%d)", (long long)n_local, nranks);
-    if (((uintptr_t)d_x & 15) != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: plane must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t hist_elems = (size_t)RSSEG_MAX_RANKS * SEL_BINS + 8;
     const size_t hist_bytes = hist_elems * sizeof(unsigned long long);
-    RSCHK(ws_reserve(ctx, hist_bytes + 256));
-    RSCHK(pin_reserve(ctx, hist_bytes));
-    unsigned long long *d_hist = (unsigned long long *)ctx->d_ws;
-    unsigned long long *d_nan = d_hist + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
-    uint32_t *d_pre = (uint32_t *)(ctx->d_ws + hist_bytes);
-    long long *h_hist = (long long *)ctx->h_pin;
+    RSCHK(ws_reserve(ctx, (size_t)P * (hist_bytes + 256)));
+    RSCHK(pin_reserve(ctx, (size_t)P * hist_bytes));
+    unsigned long long *d_hist_all = (unsigned long long *)ctx->d_ws;
+    uint32_t *d_pre_all = (uint32_t *)(ctx->d_ws + (size_t)P * hist_bytes);  // [P][64]
+    long long *h_hist_all = (long long *)ctx->h_pin;
+    if (ctx->world > 1 && (size_t)P * hist_bytes > ctx->comm_bytes)
+        return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
 
     static bool attr_done = false;
     static int sel_threads = 1024;
@@ -178,22 +178,12 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));    \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
         SEL_ATTR(256) SEL_ATTR(1024)
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
         attr_done = true;
     }
     const int threads = sel_threads;
-    int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
-    auto launch = [&](int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb) {
-#define SEL_GO(P, TH)                                                                                                             \
-    do {                                                                                                                          \
-        if (getenv("RSSEG_SEL_UNR1")) hipLaunchKernelGGL((k1_hist<P, TH, 1>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan); \
-        else hipLaunchKernelGGL((k1_hist<P, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan);  \
-    } while (0)
+    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
+    auto launch = [&](const float *d_x, int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb, unsigned long long *d_nan) {
+#define SEL_GO(PS, TH) hipLaunchKernelGGL((k1_hist<PS, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan)
 #define SEL_PASS(TH)                         \
     do {                                     \
         if (pass == 0) SEL_GO(0, TH);        \
@@ -203,76 +193,121 @@ extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n
         if (threads == 256) SEL_PASS(256);
         else SEL_PASS(1024);
     };
-    int64_t rem[RSSEG_MAX_RANKS];
-    uint32_t prefix[RSSEG_MAX_RANKS];
-    bool is_nan_rank[RSSEG_MAX_RANKS];
-    int64_t n_global = 0, n_nan = 0;
+    struct plane_state {
+        int64_t rem[RSSEG_MAX_RANKS];
+        uint32_t prefix[RSSEG_MAX_RANKS];
+        bool is_nan_rank[RSSEG_MAX_RANKS];
+        int64_t n_global, n_nan;
+        uint32_t dp[RSSEG_MAX_RANKS];
+        int ndp, slot[RSSEG_MAX_RANKS];
+    };
+    std::vector<plane_state> st((size_t)P);
+    std::vector<uint32_t> h_pre((size_t)P * 64);
 
     for (int pass = 0; pass < 3; pass++) {
-        // distinct prefixes alive in this pass
-        uint32_t dp[RSSEG_MAX_RANKS];
-        int ndp = 0, slot[RSSEG_MAX_RANKS];
-        if (pass == 0) {
-            ndp = 1;
-            for (int r = 0; r < nranks; r++) slot[r] = 0;
-        } else {
-            for (int r = 0; r < nranks; r++) {
-                slot[r] = -1;
-                if (is_nan_rank[r]) continue;
-                for (int j = 0; j < ndp; j++)
-                    if (dp[j] == prefix[r]) slot[r] = j;
-                if (slot[r] < 0) {
-                    dp[ndp] = prefix[r];
-                    slot[r] = ndp++;
+        int live = 0;
+        for (int p = 0; p < P; p++) {
+            plane_state &S = st[p];
+            S.ndp = 0;
+            if (pass == 0) {
+                S.ndp = 1;
+                for (int r = 0; r < nranks; r++) S.slot[r] = 0;
+            } else {
+                for (int r = 0; r < nranks; r++) {
+                    S.slot[r] = -1;
+                    if (S.is_nan_rank[r]) continue;
+                    for (int j = 0; j < S.ndp; j++)
+                        if (S.dp[j] == S.prefix[r]) S.slot[r] = j;
+                    if (S.slot[r] < 0) {
+                        S.dp[S.ndp] = S.prefix[r];
+                        S.slot[r] = S.ndp++;
+                    }
                 }
+                for (int j = 0; j < S.ndp; j++) h_pre[(size_t)p * 64 + j] = S.dp[j];
             }
-            if (ndp == 0) break;
-            HIPCHK(ctx, hipMemcpyAsync(d_pre, dp, sizeof(uint32_t) * ndp, hipMemcpyHostToDevice, ctx->stream));
+            live += S.ndp;
         }
-        const size_t used = ((size_t)ndp * SEL_BINS) * sizeof(unsigned long long);
-        HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_bytes, ctx->stream));
-        for (int b0 = 0; b0 < ndp; b0 += SEL_BATCH) {
-            prof_scope ps(ctx, "select");
-            const int nb_ = std::min(SEL_BATCH, ndp - b0);
-            // counters + tab1 (+ tab2: at most nb_ distinct 11-bit prefixes)
-            const size_t lds = pass == 0 ? (size_t)P0_COPIES * P0_STRIDE * sizeof(uint32_t)
-                                        : (size_t)nb_ * SEL_BINS * sizeof(uint32_t) + SEL_BINS + (pass == 2 ? (size_t)nb_ * SEL_BINS : 0);
-            unsigned long long *hb = d_hist + (size_t)b0 * SEL_BINS;
-            launch(pass, lds, pass == 0 ? d_pre : d_pre + b0, pass == 0 ? 1 : nb_, hb);
+        if (live == 0) break;
+        if (pass > 0) {
+            HIPCHK(ctx, hipMemcpyAsync(d_pre_all, h_pre.data(), sizeof(uint32_t) * h_pre.size(), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_pre is rewritten in the next pass
+        }
+        HIPCHK(ctx, hipMemsetAsync(d_hist_all, 0, (size_t)P * hist_bytes, ctx->stream));
+        for (int p = 0; p < P; p++) {
+            plane_state &S = st[p];
+            unsigned long long *d_hist = d_hist_all + (size_t)p * hist_elems;
+            unsigned long long *d_nan = d_hist + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
+            const uint32_t *d_pre = d_pre_all + (size_t)p * 64;
+            for (int b0 = 0; b0 < S.ndp; b0 += SEL_BATCH) {
+                prof_scope ps(ctx, "select");
+                const int nb_ = std::min(SEL_BATCH, S.ndp - b0);
+                // counters + tab1 (+ tab2: at most nb_ distinct 11-bit prefixes)
+                const size_t lds = pass == 0 ? (size_t)P0_COPIES * P0_STRIDE * sizeof(uint32_t)
+                                             : (size_t)nb_ * SEL_BINS * sizeof(uint32_t) + SEL_BINS + (pass == 2 ? (size_t)nb_ * SEL_BINS : 0);
+                launch(d_planes[p], pass, lds, pass == 0 ? d_pre : d_pre + b0, pass == 0 ? 1 : nb_, d_hist + (size_t)b0 * SEL_BINS, d_nan);
+            }
         }
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, pass == 0 ? hist_bytes : used, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_hist_all, d_hist_all, (size_t)P * hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (pass == 0) {
-            RSCHK(comm_allreduce_host(ctx, h_hist, (int64_t)hist_elems, RSSEG_I64, RSSEG_SUM));
-            n_nan = h_hist[(size_t)RSSEG_MAX_RANKS * SEL_BINS];
-            n_global = n_nan;
-            for (int b = 0; b < SEL_BINS; b++) n_global += h_hist[b];
+        RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * hist_elems), RSSEG_I64, RSSEG_SUM));
+        for (int p = 0; p < P; p++) {
+            plane_state &S = st[p];
+            const long long *h_hist = h_hist_all + (size_t)p * hist_elems;
+            const int64_t *rk = ranks + (size_t)p * nranks;
+            if (pass == 0) {
+                S.n_nan = h_hist[(size_t)RSSEG_MAX_RANKS * SEL_BINS];
+                S.n_global = S.n_nan;
+                for (int b = 0; b < SEL_BINS; b++) S.n_global += h_hist[b];
+                for (int r = 0; r < nranks; r++) {
+                    if (rk[r] < 0 || rk[r] >= S.n_global)
+                        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: rank %lld outside [0,%lld)", (long long)rk[r], (long long)S.n_global);
+                    S.is_nan_rank[r] = rk[r] >= S.n_global - S.n_nan;
+                    S.rem[r] = rk[r];
+                }
+            }
+            const int nbins = pass == 2 ? 1024 : SEL_BINS;
             for (int r = 0; r < nranks; r++) {
-                if (ranks[r] < 0 || ranks[r] >= n_global)
-                    return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: rank %lld outside [0,%lld)", (long long)ranks[r], (long long)n_global);
-                is_nan_rank[r] = ranks[r] >= n_global - n_nan;
-                rem[r] = ranks[r];
+                if (S.is_nan_rank[r]) continue;
+                const long long *h = h_hist + (size_t)S.slot[r] * SEL_BINS;
+                int64_t acc = 0;
+                int b = 0;
+                for (; b < nbins; b++) {
+                    if (S.rem[r] < acc + h[b]) break;
+                    acc += h[b];
+                }
+                if (b == nbins) return rs_fail(ctx, RSSEG_ERR_HIP, "order_stats: inconsistent histogram (pass %d)", pass);
+                S.rem[r] -= acc;
+                S.prefix[r] = pass == 0 ? (uint32_t)b : ((S.prefix[r] << (pass == 1 ? 11 : 10)) | (uint32_t)b);
             }
-        } else {
-            RSCHK(comm_allreduce_host(ctx, h_hist, (int64_t)ndp * SEL_BINS, RSSEG_I64, RSSEG_SUM));
-        }
-        const int nbins = pass == 2 ? 1024 : SEL_BINS;
-        for (int r = 0; r < nranks; r++) {
-            if (is_nan_rank[r]) continue;
-            const long long *h = h_hist + (size_t)slot[r] * SEL_BINS;
-            int64_t acc = 0;
-            int b = 0;
-            for (; b < nbins; b++) {
-                if (rem[r] < acc + h[b]) break;
-                acc += h[b];
-            }
-            if (b == nbins) return rs_fail(ctx, RSSEG_ERR_HIP, "order_stats: inconsistent histogram (pass %d)", pass);
-            rem[r] -= acc;
-            prefix[r] = pass == 0 ? (uint32_t)b : ((prefix[r] << (pass == 1 ? 11 : 10)) | (uint32_t)b);
         }
     }
-    for (int r = 0; r < nranks; r++) out_values[r] = is_nan_rank[r] ? __builtin_nanf("") : key_to_f32(prefix[r]);
-    if (n_nan_out) *n_nan_out = n_nan;
+    for (int p = 0; p < P; p++) {
+        for (int r = 0; r < nranks; r++)
+            out_values[(size_t)p * nranks + r] = st[p].is_nan_rank[r] ? __builtin_nanf("") : key_to_f32(st[p].prefix[r]);
+        if (n_nan_out) n_nan_out[p] = st[p].n_nan;
+    }
     return RSSEG_OK;
+}
+
+extern "C" int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, const int64_t *ranks, int nranks,
+                                     float *out_values, int64_t *n_nan_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || n_local < 0 || !ranks || !out_values || nranks < 1 || nranks > RSSEG_MAX_RANKS)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: bad arguments (n=%lld nranks=%d)", (long long)n_local, nranks);
+    if (((uintptr_t)d_x & 15) != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: plane must be 16-byte aligned");
+    return order_stats_core(ctx, &d_x, 1, n_local, ranks, nranks, out_values, n_nan_out);
+}
+
+extern "C" int rsseg_order_stats_multi_f32(rsseg_ctx *ctx, const float *const *d_planes, int nplanes, int64_t n_local,
+                                           const int64_t *ranks, int nranks, float *out_values, int64_t *n_nan_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_planes || nplanes < 1 || nplanes > SEL_MAX_PLANES || n_local < 0 || !ranks || !out_values || nranks < 1 || nranks > RSSEG_MAX_RANKS)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats_multi: bad arguments (planes=%d n=%lld nranks=%d)", nplanes, (long long)n_local, nranks);
+    for (int p = 0; p < nplanes; p++)
+        if (!d_planes[p] || ((uintptr_t)d_planes[p] & 15) != 0)
+            return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats_multi: plane %d null or not 16-byte aligned", p);
+    return order_stats_core(ctx, d_planes, nplanes, n_local, ranks, nranks, out_values, n_nan_out);
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rsseg_prof_reset": (_int, [_vp]),
     "rsseg_prof_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "rsseg_order_stats_f32": (_int, [_vp, _vp, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
+    "rsseg_order_stats_multi_f32": (_int, [_vp, C.POINTER(_vp), _int, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
     "rsseg_normalize_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
     "rsseg_spectral_indices_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP]),
     "rsseg_pca_fit_transform_f32": (_int, [_vp, _PP, _int, _i64, C.POINTER(C.c_float), C.POINTER(C.c_double), _int, _PP,

@@ -28,42 +28,55 @@ def band_lohi(ctx: Context, bands: Sequence, n_global: Optional[int] = None) -> 
     return out
 
 
-def band_quantile_bundle(ctx: Context, band, n_global: Optional[int] = None):
-    """Everything the stage needs from ONE band's order statistics, with ONE select (3 passes over the plane):
+def band_quantile_bundles(ctx: Context, bands: Sequence, n_global: Optional[int] = None) -> List[dict]:
+    """Everything the stage needs from the order statistics of each band, with ONE grouped select (3 passes over each
+    plane, 3 host synchronisations / all-reduces for the whole group):
       lo, hi          np.percentile(band, 2 / 98)                      (robust_normalize, indices.py:38-39)
       center, scale   RobustScaler statistics of the NORMALISED band  (indices.py:230-231)
       lo2, hi2        np.percentile(normalised band, 2 / 98)         (the texture functions re-normalise, :265)
     The normalisation f(v) = (clip(v, lo, hi) - lo) / (hi - lo + 1e-10) is monotone non-decreasing in float32
     arithmetic, so the k-th smallest normalised value is f(k-th smallest raw value): the quantiles of the
     normalised band follow from the raw band's order statistics pushed through f on the host (same float32
-    operations as the K2 kernel).  Falls back to separate selects when the band holds NaNs."""
-    from .quantiles import median_plan, percentile_plan, robust_scaler_stats
-    n = int(band.numel()) if n_global is None else int(n_global)
+    operations as the K2 kernel).  A band that holds NaNs falls back to separate selects."""
+    from .quantiles import median_plan, percentile_plan
+    n = int(bands[0].numel()) if n_global is None else int(n_global)
     p2r, p2f = percentile_plan(n, 2, np.float32, True)
     p98r, p98f = percentile_plan(n, 98, np.float32, True)
     mr, mf = median_plan(n, np.float32)
     qr, qf = percentile_plan(n, (25.0, 75.0), np.float32, False)
-    vals, n_nan = ctx.order_stats(band, p2r + p98r + mr + qr)
-    if n_nan > 0:
-        lo, hi = band_percentiles(ctx, band, (2, 98), n_global)
-        return dict(lo=lo, hi=hi, center=None, scale=None, lo2=None, hi2=None)
-    o = 0
-    parts = []
-    for r in (p2r, p98r, mr, qr):
-        parts.append(vals[o:o + len(r)])
-        o += len(r)
-    lo, hi = p2f(parts[0]), p98f(parts[1])
-    den = hi - lo + 1e-10  # float32, as in robust_normalize
+    ranks = p2r + p98r + mr + qr
+    out: List[dict] = []
+    for g0 in range(0, len(bands), 8):
+        group = list(bands[g0:g0 + 8])
+        vals_all, nan_all = ctx.order_stats_multi(group, [ranks] * len(group))
+        for band, vals, n_nan in zip(group, vals_all, nan_all):
+            if n_nan > 0:
+                lo, hi = band_percentiles(ctx, band, (2, 98), n_global)
+                out.append(dict(lo=lo, hi=hi, center=None, scale=None, lo2=None, hi2=None))
+                continue
+            o = 0
+            parts = []
+            for r in (p2r, p98r, mr, qr):
+                parts.append(vals[o:o + len(r)])
+                o += len(r)
+            lo, hi = p2f(parts[0]), p98f(parts[1])
+            den = hi - lo + 1e-10  # float32, as in robust_normalize
 
-    def f(v):
-        return (np.clip(v, lo, hi) - lo) / den
+            def f(v, lo=lo, hi=hi, den=den):
+                return (np.clip(v, lo, hi) - lo) / den
 
-    center = np.float32(mf(f(parts[2])))
-    q = qf(f(parts[3]))
-    scale = np.float64(q[1] - q[0])
-    if scale < 10 * np.finfo(np.float64).eps:
-        scale = np.float64(1.0)
-    return dict(lo=lo, hi=hi, center=center, scale=scale, lo2=p2f(f(parts[0])), hi2=p98f(f(parts[1])))
+            center = np.float32(mf(f(parts[2])))
+            q = qf(f(parts[3]))
+            scale = np.float64(q[1] - q[0])
+            if scale < 10 * np.finfo(np.float64).eps:
+                scale = np.float64(1.0)
+            out.append(dict(lo=lo, hi=hi, center=center, scale=scale, lo2=p2f(f(parts[0])), hi2=p98f(f(parts[1]))))
+    return out
+
+
+def band_quantile_bundle(ctx: Context, band, n_global: Optional[int] = None):
+    """band_quantile_bundles for one band."""
+    return band_quantile_bundles(ctx, [band], n_global)[0]
 
 
 def normalize_bands(ctx: Context, bands: Sequence, lohi: np.ndarray) -> List:
@@ -115,7 +128,7 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
     """The 19 planes of hierarchical_features['all'] (scripts/2:112-127), in stack order.
     Returns (planes, dtypes_note): all planes float32 except index 16 (gradient_5) which is uint8 on
     the device and becomes uint8/255.0 (float64) on the host, as in indices.py:440."""
-    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    qb = band_quantile_bundles(ctx, bands, n_global)
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
@@ -171,7 +184,12 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     (profiles/r01_overlap_note.md): the GLCM kernel fills every CU and slows down by what the other stream
     executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default."""
     NIR = 3
-    qn = band_quantile_bundle(ctx, bands[NIR], n_global)
+    if overlap:   # the NIR band's statistics first, so that its texture chain can start beside the rest
+        qn = band_quantile_bundle(ctx, bands[NIR], n_global)
+        qb = None
+    else:
+        qb = band_quantile_bundles(ctx, bands, n_global)
+        qn = qb[NIR]
     fused = qn["center"] is not None
     nir_norm = ctx.normalize(bands[NIR], float(qn["lo"]), float(qn["hi"]))
     if fused:
@@ -183,7 +201,9 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     if overlap:
         g.torch_stream.wait_stream(ctx.torch_stream)
     glcm, _ = glcm_features(g, nir2, H, W, 32, glcm_window, glcm_step)   # asynchronous on the aux stream
-    qb = [qn if i == NIR else band_quantile_bundle(ctx, b, n_global) for i, b in enumerate(bands)]
+    if qb is None:
+        rest = band_quantile_bundles(ctx, [b for i, b in enumerate(bands) if i != NIR], n_global)
+        qb = rest[:NIR] + [qn] + rest[NIR:]
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
@@ -227,7 +247,7 @@ def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: 
     texture windows read (glcm_halo_rows).  Percentiles, PCA and KMeans reduce over all ranks through the
     context's all-reduce hook; the label stripe equals rows [r0, r1) of the single-GPU result bit for bit."""
     n_global = H * W
-    qb = [band_quantile_bundle(ctx, b, n_global) for b in bands]
+    qb = band_quantile_bundles(ctx, bands, n_global)
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]

@@ -84,7 +84,7 @@ class Context:
         torch = _torch()
         import torch.distributed as dist
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self._comm_buf = torch.zeros(1 << 21, dtype=torch.uint8, device=self.device)
+        self._comm_buf = torch.zeros(1 << 22, dtype=torch.uint8, device=self.device)
         self._hook = L.ALLREDUCE_FN(make_allreduce_hook(self._comm_buf, group))
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
@@ -174,6 +174,18 @@ class Context:
         self._chk(self.lib.rsseg_order_stats_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), r, len(ranks), out,
                                                  C.byref(nn)))
         return np.array(out[:], dtype=np.float32), nn.value
+
+    def order_stats_multi(self, planes: Sequence, ranks: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+        """Order statistics of several planes of equal length in one call (<= 8 planes, the same number of ranks for
+        each): (values [P, R] float32, n_nan [P])."""
+        P, R = len(planes), len(ranks[0])
+        if any(len(r) != R for r in ranks) or any(p.numel() != planes[0].numel() for p in planes):
+            raise ValueError("order_stats_multi: planes / rank lists of unequal length")
+        flat = (C.c_int64 * (P * R))(*[int(x) for r in ranks for x in r])
+        out = (C.c_float * (P * R))()
+        nn = (C.c_int64 * P)()
+        self._chk(self.lib.rsseg_order_stats_multi_f32(self.h, self._pp(planes), P, planes[0].numel(), flat, R, out, nn))
+        return np.array(out[:], dtype=np.float32).reshape(P, R), np.array(nn[:], dtype=np.int64)
 
     # ---- K2 ------------------------------------------------------------------------------------
     def normalize(self, plane, lo: float, hi: float, out=None):

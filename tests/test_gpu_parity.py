@@ -425,6 +425,26 @@ def test_forest_deep_synthetic_vs_oracle(ctx, oracle):
     assert np.array_equal(got, want)
 
 
+def test_order_stats_multi_equals_single(ctx, scene, oracle):
+    """The grouped select (all planes advance pass by pass together) returns what one select per plane returns,
+    including a plane with NaNs and planes whose ranks fall into the same and into different radix prefixes."""
+    bands = oracle.stage1_preprocess(scene["dn"])
+    planes = [bands[i].reshape(-1).copy() for i in range(7)]
+    planes[2][::97] = np.nan
+    planes.append(np.linspace(-3.0, 5.0, planes[0].size, dtype=np.float32))
+    n = planes[0].size
+    dv = [dev(ctx, p) for p in planes]
+    ranks = [[0, n // 50, n // 2, n // 2 + 1, n - 1 - 4000, (7 * i) % (n - 4000)] for i in range(len(planes))]
+    vals, nans = ctx.order_stats_multi(dv, ranks)
+    for i, d in enumerate(dv):
+        v1, nn1 = ctx.order_stats(d, ranks[i])
+        assert np.array_equal(vals[i], v1, equal_nan=True) and nans[i] == nn1, i
+        srt = np.sort(planes[i])
+        assert np.array_equal(vals[i], srt[ranks[i]], equal_nan=True), i
+    with pytest.raises(ValueError):
+        ctx.order_stats_multi(dv + dv[:1], ranks + ranks[:1])  # more than 8 planes
+
+
 def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
     """One select per band (config-3 fast path) gives the same six statistics as the separate NumPy-style
     calls on the raw and on the normalised band."""
