@@ -1112,49 +1112,65 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         // km_kpp_chunk for the chunks the samples fall into
         RSCHK(upload_cands(nullptr, 0, C[c - 1]));
         int64_t cand_idx[KPP_MAXL];
-        double found[KPP_MAXL];
+        // xbuf[l] = {global pixel index, its F scaled+centred values}: filled by the rank that owns the pixel, zeros
+        // elsewhere, so ONE sum all-reduce hands every rank both the sampled indices and the candidate rows
+        double xbuf[KPP_MAXL * (1 + RSSEG_MAX_FEATURES)];
+        memset(xbuf, 0, sizeof(xbuf));
+        int last_rank = 0;
+        for (int rk = 0; rk < ctx->world; rk++)
+            if (n_all[rk] > 0) last_rank = rk;
         for (int l = 0; l < L; l++) {
             const double r = rng.random_sample() * (double)current_pot;  // uniform(size=L) * current_pot
             const long double rl = ceill((long double)r * 1099511627776.0L);
             const u128 target = rl <= 0 ? (u128)0 : (u128)rl;
             // owner rank: first rank whose inclusive prefix reaches the target
-            found[l] = 0.0;
             u128 before = 0;
             int owner = -1;
             for (int rk = 0; rk < ctx->world; rk++) {
                 if (n_all[rk] > 0 && before + rank_tot[rk] >= target) { owner = rk; break; }
                 before += rank_tot[rk];
             }
-            if (owner < 0) {  // beyond the total: np.clip(candidate_ids, None, N-1)
-                if (ctx->rank == 0) found[l] = (double)(N - 1);
-                continue;
+            int64_t li;  // local index of the sampled pixel on its owner
+            if (owner < 0) {  // beyond the total: np.clip(candidate_ids, None, N-1) -> the last pixel of the last stripe
+                if (ctx->rank != last_rank) continue;
+                li = n - 1;
+            } else {
+                if (owner != ctx->rank) continue;
+                u128 run = before;
+                int64_t ch = 0;
+                for (; ch < nchunks; ch++) {
+                    if (run + prefix_part[ch] >= target) break;
+                    run += prefix_part[ch];
+                }
+                if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
+                const int64_t c0 = ch * CHUNK, cn = std::min<int64_t>(CHUNK, n - c0);
+                hipLaunchKernelGGL((km_kpp_chunk<T>), dim3((unsigned)ceil_div64(cn, KM_THREADS)), dim3(KM_THREADS), 0, st, pl, F, c0, cn, d_sp,
+                                   d_cand, d_cc, (const T *)d_closest, c > 1 ? 1 : 0, d_chunk);
+                HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_chunk, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                const T *hv = (const T *)ctx->h_pin;
+                int64_t lc = cn - 1;
+                for (int64_t i = 0; i < cn; i++) {
+                    run += (u128)(unsigned long long)llrint((double)hv[i] * 1099511627776.0);
+                    if (run >= target) { lc = i; break; }
+                }
+                li = c0 + lc;
             }
-            if (owner != ctx->rank) continue;
-            u128 run = before;
-            int64_t ch = 0;
-            for (; ch < nchunks; ch++) {
-                if (run + prefix_part[ch] >= target) break;
-                run += prefix_part[ch];
-            }
-            if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
-            const int64_t c0 = ch * CHUNK, cn = std::min<int64_t>(CHUNK, n - c0);
-            hipLaunchKernelGGL((km_kpp_chunk<T>), dim3((unsigned)ceil_div64(cn, KM_THREADS)), dim3(KM_THREADS), 0, st, pl, F, c0, cn, d_sp, d_cand,
-                               d_cc, (const T *)d_closest, c > 1 ? 1 : 0, d_chunk);
+            double *xb = xbuf + (size_t)l * (1 + F);
+            xb[0] = (double)(offset + li);
+            hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li, d_sp, d_row);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_chunk, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            const T *hv = (const T *)ctx->h_pin;
-            int64_t li = cn - 1;
-            for (int64_t i = 0; i < cn; i++) {
-                run += (u128)(unsigned long long)llrint((double)hv[i] * 1099511627776.0);
-                if (run >= target) { li = i; break; }
-            }
-            found[l] = (double)(offset + c0 + li);
+            for (int f = 0; f < F; f++) xb[1 + f] = (double)((const T *)ctx->h_pin)[f];
         }
-        RSCHK(comm_allreduce_host(ctx, found, L, RSSEG_F64, RSSEG_SUM));
-        for (int l = 0; l < L; l++) cand_idx[l] = (int64_t)found[l];
+        RSCHK(comm_allreduce_host(ctx, xbuf, (int64_t)L * (1 + F), RSSEG_F64, RSSEG_SUM));
         T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
-        RSCHK(fetch_rows(cand_idx, L, rows));
+        for (int l = 0; l < L; l++) {
+            cand_idx[l] = (int64_t)xbuf[(size_t)l * (1 + F)];
+            for (int f = 0; f < F; f++) rows[l][f] = (T)xbuf[(size_t)l * (1 + F) + 1 + f];
+        }
         RSCHK(upload_cands(rows, L, C[c - 1]));
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
