@@ -62,19 +62,43 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
 
 def save_feature_outputs(output_dir: str, features_dict: Dict, hierarchical_features: Dict, height: int, width: int,
                          transform=None, crs=None) -> Dict[str, str]:
-    """File names and contents of scripts/2:193-232."""
+    """File names and contents of scripts/2:193-258: the three .npy stacks, the pickle, and the full stack as
+    all_hierarchical_features.tif (one band per feature, float64, georeferenced with `transform` / `crs`; written as
+    uncompressed strips where the reference asks rasterio for tiled LZW — same raster once read back).
+    `crs`: an EPSG integer, 'EPSG:xxxx', or an object with to_epsg()."""
     os.makedirs(output_dir, exist_ok=True)
     paths = {"level1": os.path.join(output_dir, "level1_features.npy"),
              "level2": os.path.join(output_dir, "level2_features.npy"),
              "all": os.path.join(output_dir, "all_hierarchical_features.npy"),
-             "pkl": os.path.join(output_dir, "all_features_and_metadata.pkl")}
+             "pkl": os.path.join(output_dir, "all_features_and_metadata.pkl"),
+             "tif": os.path.join(output_dir, "all_hierarchical_features.tif")}
     np.save(paths["level1"], hierarchical_features["level_1"])
     np.save(paths["level2"], hierarchical_features["level_2"])
     np.save(paths["all"], hierarchical_features["all"])
     with open(paths["pkl"], "wb") as f:
         pickle.dump({"hierarchical_features": hierarchical_features, "all_extracted_features_dict": features_dict,
                      "dimensions": (height, width), "geo_transform": transform, "crs": crs}, f)
+    from .tiff import write_tiff
+    write_tiff(paths["tif"], np.ascontiguousarray(np.moveaxis(hierarchical_features["all"], -1, 0)), transform=transform,
+               epsg=_epsg_of(crs))
     return paths
+
+
+def _epsg_of(crs) -> Optional[int]:
+    if crs is None:
+        return None
+    if hasattr(crs, "to_epsg"):
+        return crs.to_epsg()
+    if isinstance(crs, str) and crs.upper().startswith("EPSG:"):
+        return int(crs.split(":")[1])
+    return int(crs)
+
+
+def save_class_map_tif(class_map: np.ndarray, out_tif: str, transform=None, crs=None) -> str:
+    """The uint8 label GeoTIFF of scripts/3:509-538 (nodata 0; the colour table is not written)."""
+    from .tiff import write_tiff
+    write_tiff(out_tif, np.asarray(class_map).astype(np.uint8), transform=transform, epsg=_epsg_of(crs), nodata=0)
+    return out_tif
 
 
 def run_kmeans_stage(hierarchical_all: np.ndarray, n_clusters: int = 7, ctx: Optional[Context] = None) -> np.ndarray:

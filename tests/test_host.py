@@ -87,6 +87,44 @@ def test_kmeans_draws_other_seeds():
             assert cid == int(rs.choice(n, p=w / w.sum())), (seed, n)
 
 
+def test_geotiff_tags_roundtrip(tmp_path):
+    """transform / EPSG / nodata survive a write-read cycle; tag layout is valid TIFF (sorted tags, even offsets)."""
+    import struct
+    from rsseg.tiff import read_tiff, read_tiff_georef, write_tiff
+    a = (np.arange(3 * 5 * 7) % 251).astype(np.uint8).reshape(3, 5, 7)
+    p = str(tmp_path / "g.tif")
+    tr = (30.0, 0.0, 500000.0, 0.0, -30.0, 4100000.0)
+    write_tiff(p, a, transform=tr, epsg=32650, nodata=0)
+    assert np.array_equal(read_tiff(p), a)
+    g = read_tiff_georef(p)
+    assert g["transform"] == tr and g["epsg"] == 32650 and g["nodata"] == 0.0
+    buf = open(p, "rb").read()
+    (off,) = struct.unpack_from("<I", buf, 4)
+    (n,) = struct.unpack_from("<H", buf, off)
+    tags = [struct.unpack_from("<H", buf, off + 2 + 12 * i)[0] for i in range(n)]
+    assert tags == sorted(tags) and {33550, 33922, 34735, 42113} <= set(tags)
+    rot = (10.0, 2.0, 100.0, -1.5, -10.0, 900.0)   # rotated grid -> ModelTransformation
+    write_tiff(p, a.astype(np.float64), transform=rot, epsg=4326, nodata=-9999.5)
+    g = read_tiff_georef(p)
+    assert g["transform"] == rot and g["epsg"] == 4326 and g["nodata"] == -9999.5
+    write_tiff(p, a)
+    assert read_tiff_georef(p) == {"transform": None, "epsg": None, "nodata": None}
+
+
+def test_stage_geotiff_outputs(tmp_path):
+    from rsseg import stages
+    from rsseg.tiff import read_tiff, read_tiff_georef
+    rng = np.random.default_rng(0)
+    hier = {"level_1": rng.random((6, 9, 14)), "level_2": rng.random((6, 9, 5)), "all": rng.random((6, 9, 19))}
+    tr = (30.0, 0.0, 1000.0, 0.0, -30.0, 2000.0)
+    paths = stages.save_feature_outputs(str(tmp_path), {"ndvi": np.zeros((6, 9), np.float32)}, hier, 6, 9, transform=tr, crs="EPSG:32650")
+    back = read_tiff(paths["tif"])
+    assert back.shape == (19, 6, 9) and back.dtype == np.float64 and np.array_equal(np.moveaxis(back, 0, -1), hier["all"])
+    assert read_tiff_georef(paths["tif"])["epsg"] == 32650
+    out = stages.save_class_map_tif(np.arange(54).reshape(6, 9) % 4, str(tmp_path / "cls.tif"), transform=tr, crs=32650)
+    assert read_tiff(out).dtype == np.uint8 and read_tiff_georef(out)["nodata"] == 0.0
+
+
 def test_tiff_roundtrip_and_bundled_layout(tmp_path, golden_dir):
     from rsseg.tiff import read_tiff, write_tiff
     dn = np.load(os.path.join(golden_dir, "scene_aa.npz"))["dn"]
