@@ -67,6 +67,11 @@ int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out);
 void rsseg_ctx_destroy(rsseg_ctx *ctx);
 const char *rsseg_last_error(const rsseg_ctx *ctx);
 const char *rsseg_version(void);
+/* While on, the spectral-index call (7 index planes), the two bilinear-upsample calls (1 plane) and the PCA call
+ * (n_components planes) also reduce the minimum and maximum of every plane they write, NaN counted
+ * as 0 (what KMeans' MinMaxScaler sees); rsseg_ctx_last_minmax returns them, by output index, until the next such call. */
+int rsseg_ctx_collect_minmax(rsseg_ctx *ctx, int on);
+int rsseg_ctx_last_minmax(rsseg_ctx *ctx, int plane, double *mn, double *mx);
 /* Asynchronous mode: entry points whose results stay on the device (normalize, indices, quantize, glcm, resize,
  * window operators, forest_predict) return right after enqueueing on the context's stream; rsseg_ctx_sync waits.
  * Used to run the VALU-bound GLCM on a second stream beside the HBM-bound passes (rsseg/pipeline.py). */
@@ -197,6 +202,11 @@ typedef struct rsseg_kmeans_info {
 int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local,
                              int k, uint32_t seed, int max_iter, double tol, int32_t *d_labels,
                              double *centers, rsseg_kmeans_info *info);
+/* The same when the caller already knows this rank's minimum and maximum of every plane (NaN counted as 0), e.g. from
+ * rsseg_ctx_last_minmax: the MinMaxScaler pass over the planes is skipped (the extrema are still all-reduced). */
+int rsseg_kmeans_fit_predict_mm(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k,
+                                uint32_t seed, int max_iter, double tol, int32_t *d_labels, double *centers,
+                                rsseg_kmeans_info *info, const double *local_min, const double *local_max);
 
 /* ---- K11: random-forest inference ---------------------------------------------------------- */
 /* Flattened sklearn forest (tree_ arrays concatenated; children are tree-local, -1 = leaf).

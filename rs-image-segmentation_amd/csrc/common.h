@@ -50,7 +50,15 @@ struct rsseg_ctx {
     std::map<std::string, prof_entry> prof;
     std::vector<hipEvent_t> event_pool;
     forest_dev forest;
+    // optional per-plane extrema of the planes the last producing call wrote (rsseg_ctx_collect_minmax)
+    bool mm_collect = false;
+    uint32_t *d_mm = nullptr;  // [RSSEG_MM_PLANES][2] ordered keys {min, max}
+    int mm_count = 0;
+    double mm_min[8], mm_max[8];
 };
+#define RSSEG_MM_PLANES 8
+int mm_begin(rsseg_ctx *ctx, int nplanes);   // reset the device slots before a producing launch (no-op when off)
+int mm_end(rsseg_ctx *ctx, int nplanes);     // read them back into ctx->mm_min / mm_max (after the launch)
 
 int rs_fail(rsseg_ctx *ctx, int code, const char *fmt, ...);
 #define HIPCHK(ctx, expr)                                                                      \
@@ -118,6 +126,27 @@ __device__ __forceinline__ double wave_max(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// ---- running extrema of a produced plane (NaN counts as 0, as the KMeans scaler sees it) -----------------------
+// monotone map float -> uint32 (as in k1_select.hip); atomicMin / atomicMax on the keys
+__device__ __forceinline__ uint32_t mm_key(float x)
+{
+    if (x != x) x = 0.f;
+    uint32_t u = __float_as_uint(x);
+    if (u == 0x80000000u) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// per-wave reduction, then at most one atomic per wave and only when it improves the current global value
+__device__ __forceinline__ void mm_commit(uint32_t *slot, float mn, float mx)
+{
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane_id() == 0) {
+        const uint32_t kmn = mm_key(mn), kmx = mm_key(mx);
+        if (kmn < __builtin_nontemporal_load(&slot[0])) atomicMin(&slot[0], kmn);
+        if (kmx > __builtin_nontemporal_load(&slot[1])) atomicMax(&slot[1], kmx);
+    }
 }
 
 // round-to-nearest-even fixed point, quantum 2^-40, exact for |x| < 2^11:

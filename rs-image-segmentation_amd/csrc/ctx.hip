@@ -70,6 +70,7 @@ extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->d_mm) (void)hipFree(ctx->d_mm);
     if (ctx->forest.d_nodes) (void)hipFree(ctx->forest.d_nodes);
     if (ctx->forest.d_leafval) (void)hipFree(ctx->forest.d_leafval);
     if (ctx->forest.d_treeoff) (void)hipFree(ctx->forest.d_treeoff);
@@ -162,6 +163,58 @@ int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, in
         e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         e.launches++;
     }
+    return RSSEG_OK;
+}
+
+// ---- extrema of produced planes ------------------------------------------------------------
+extern "C" int rsseg_ctx_collect_minmax(rsseg_ctx *ctx, int on)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->d_mm) HIPCHK(ctx, hipMalloc((void **)&ctx->d_mm, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES));
+    ctx->mm_collect = on != 0;
+    ctx->mm_count = 0;
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_ctx_last_minmax(rsseg_ctx *ctx, int plane, double *mn, double *mx)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (plane < 0 || plane >= ctx->mm_count) return rs_fail(ctx, RSSEG_ERR_INVALID, "last_minmax: plane %d of %d", plane, ctx->mm_count);
+    if (mn) *mn = ctx->mm_min[plane];
+    if (mx) *mx = ctx->mm_max[plane];
+    return RSSEG_OK;
+}
+
+int mm_begin(rsseg_ctx *ctx, int nplanes)
+{
+    ctx->mm_count = 0;
+    if (!ctx->mm_collect) return RSSEG_OK;
+    uint32_t init[2 * RSSEG_MM_PLANES];
+    for (int i = 0; i < RSSEG_MM_PLANES; i++) { init[2 * i] = 0xffffffffu; init[2 * i + 1] = 0u; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // init lives on this stack frame
+    (void)nplanes;
+    return RSSEG_OK;
+}
+
+int mm_end(rsseg_ctx *ctx, int nplanes)
+{
+    if (!ctx->mm_collect) return RSSEG_OK;
+    uint32_t k[2 * RSSEG_MM_PLANES];
+    HIPCHK(ctx, hipMemcpyAsync(k, ctx->d_mm, sizeof(k), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    auto unkey = [](uint32_t key) {
+        uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+        float f;
+        memcpy(&f, &u, 4);
+        return (double)f;
+    };
+    for (int i = 0; i < nplanes && i < RSSEG_MM_PLANES; i++) {
+        ctx->mm_min[i] = unkey(k[2 * i]);      // an untouched slot decodes to NaN (keys 0xffffffff / 0): empty plane
+        ctx->mm_max[i] = unkey(k[2 * i + 1]);
+    }
+    ctx->mm_count = nplanes < RSSEG_MM_PLANES ? nplanes : RSSEG_MM_PLANES;
     return RSSEG_OK;
 }
 

@@ -61,9 +61,14 @@ __device__ __forceinline__ void k2_pixel(const float nb[5], float o[7])
     }
 }
 
-__global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n)
+// MM: also reduce min / max of the 7 index planes into mm[j] (rsseg_ctx_collect_minmax)
+template <bool MM>
+__global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, uint32_t *__restrict__ mm)
 {
     const int64_t n4 = n >> 2;
+    float lmn[7], lmx[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { lmn[j] = INFINITY; lmx[j] = -INFINITY; }
     for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
         float4 b[5];
 #pragma unroll
@@ -77,6 +82,16 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n)
         }
 #pragma unroll
         for (int p = 0; p < 4; p++) k2_pixel(nb[p], o[p]);
+        if (MM) {
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float v = o[p][j] != o[p][j] ? 0.f : o[p][j];
+                    lmn[j] = fminf(lmn[j], v);
+                    lmx[j] = fmaxf(lmx[j], v);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 7; j++)
             if (a.out[j]) reinterpret_cast<float4 *>(a.out[j])[i] = make_float4(o[0][j], o[1][j], o[2][j], o[3][j]);
@@ -94,12 +109,24 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n)
             nb[j] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
         }
         k2_pixel(nb, o);
+        if (MM) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const float v = o[j] != o[j] ? 0.f : o[j];
+                lmn[j] = fminf(lmn[j], v);
+                lmx[j] = fmaxf(lmx[j], v);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 7; j++)
             if (a.out[j]) a.out[j][t] = o[j];
 #pragma unroll
         for (int j = 0; j < 5; j++)
             if (a.norm[j]) a.norm[j][t] = nb[j];
+    }
+    if (MM) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) mm_commit(mm + 2 * j, lmn[j], lmx[j]);
     }
 }
 
@@ -189,11 +216,14 @@ extern "C" int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_
         if (a.out[j] && ((uintptr_t)a.out[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: output plane unaligned");
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    RSCHK(mm_begin(ctx, 7));
     {
         prof_scope ps(ctx, "indices");
-        hipLaunchKernelGGL(k2_indices, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n);
+        if (ctx->mm_collect) hipLaunchKernelGGL(k2_indices<true>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n, ctx->d_mm);
+        else hipLaunchKernelGGL(k2_indices<false>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n, (uint32_t *)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());
+    RSCHK(mm_end(ctx, 7));
     return stream_sync(ctx);
 }
 

@@ -120,10 +120,13 @@ struct proj_args {
 
 // Specialised on the band count; the component loop stays rolled so that only one component's coefficients are
 // held in scalar registers at a time (with everything unrolled the two argument blocks no longer fit the SGPR file).
-template <int NB>
-__global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args pr, int64_t n)
+template <int NB, bool MM>
+__global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args pr, int64_t n, uint32_t *__restrict__ mm)
 {
     const int64_t n4 = n >> 2;
+    float lmn[PCA_MAXB], lmx[PCA_MAXB];  // MM: running extrema per component (indexed by the rolled loop: LDS-free, registers)
+#pragma unroll
+    for (int c = 0; c < PCA_MAXB; c++) { lmn[c] = INFINITY; lmx[c] = -INFINITY; }
     for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
         float4 v[NB];
 #pragma unroll
@@ -147,6 +150,18 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
                 y[p] = s - pr.offs[c];
             }
             reinterpret_cast<float4 *>(pr.out[c])[i] = make_float4(y[0], y[1], y[2], y[3]);
+            if (MM) {
+                float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float v = y[p] != y[p] ? 0.f : y[p];
+                    lo = fminf(lo, v);
+                    hi = fmaxf(hi, v);
+                }
+#pragma unroll
+                for (int cc = 0; cc < PCA_MAXB; cc++)  // static indices: the arrays stay in registers
+                    if (cc == c) { lmn[cc] = fminf(lmn[cc], lo); lmx[cc] = fmaxf(lmx[cc], hi); }
+            }
         }
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
@@ -159,8 +174,20 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
             float s = 0.f;
 #pragma unroll
             for (int b = 0; b < NB; b++) s = __fmaf_rn(x[b], pr.comp[c][b], s);
-            pr.out[c][t] = s - pr.offs[c];
+            const float yv = s - pr.offs[c];
+            pr.out[c][t] = yv;
+            if (MM) {
+                const float v = yv != yv ? 0.f : yv;
+#pragma unroll
+                for (int cc = 0; cc < PCA_MAXB; cc++)
+                    if (cc == c) { lmn[cc] = fminf(lmn[cc], v); lmx[cc] = fmaxf(lmx[cc], v); }
+            }
         }
+    }
+    if (MM) {
+#pragma unroll
+        for (int cc = 0; cc < PCA_MAXB; cc++)
+            if (cc < pr.nc) mm_commit(mm + 2 * cc, lmn[cc], lmx[cc]);
     }
 }
 
@@ -336,16 +363,22 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
     if (mean)
         for (int b = 0; b < nb; b++) mean[b] = mu[b];
     if (d_out && n_local > 0) {
+        RSCHK(mm_begin(ctx, n_components));
         {
             prof_scope ps(ctx, "project");
             const dim3 pg((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
             switch (nb) {
-#define PROJ_GO(NBV) case NBV: hipLaunchKernelGGL(k3_project<NBV>, pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local); break;
+#define PROJ_GO(NBV)                                                                                                               \
+    case NBV:                                                                                                                      \
+        if (ctx->mm_collect) hipLaunchKernelGGL((k3_project<NBV, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, ctx->d_mm); \
+        else hipLaunchKernelGGL((k3_project<NBV, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, (uint32_t *)nullptr);      \
+        break;
                 PROJ_GO(1) PROJ_GO(2) PROJ_GO(3) PROJ_GO(4) PROJ_GO(5) PROJ_GO(6) PROJ_GO(7) PROJ_GO(8)
 #undef PROJ_GO
             }
         }
         HIPCHK(ctx, hipGetLastError());
+        RSCHK(mm_end(ctx, n_components));
     }
     return stream_sync(ctx);
 }

@@ -195,14 +195,9 @@ __global__ __launch_bounds__(256) void k8_div(float *__restrict__ x, int64_t n, 
 // Row-striped form: the local source holds rows [src_row0, src_row0 + sh_local) of a source sh rows tall and the
 // local destination rows [dst_row0, dst_row0 + dh_local) of a destination dh rows tall; taps are computed in
 // GLOBAL coordinates, so a stripe gets exactly the values of the un-sharded call.
-__global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, int sh, int sw, float *__restrict__ dst, int dh,
-                                                 int dw, double scale_x, double scale_y, int src_row0, int dst_row0, int dh_local)
+__device__ __forceinline__ float resize_px(const float *__restrict__ src, int sh, int sw, double scale_x, double scale_y, int src_row0,
+                                           int px, int py)
 {
-    // (Sharing the right-hand tap with the next lane by shuffle, and four pixels per lane with one 16-byte store,
-    // were both measured slower than this plain form: 0.80 / 0.95 ms against 0.72 ms per 16384^2 plane.)
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), pyl = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= dw || pyl >= dh_local) return;
-    const int py = pyl + dst_row0;
     float fx = (float)(((double)px + 0.5) * scale_x - 0.5);
     int sx = (int)floorf(fx);
     fx = fx - (float)sx;
@@ -220,7 +215,33 @@ __global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, 
     const float t00 = r0[sx] * a0, t01 = r0[sx1] * a1, t10 = r1[sx] * a0, t11 = r1[sx1] * a1;
     const float h0 = t00 + t01, h1 = t10 + t11;
     const float u0 = h0 * b0, u1 = h1 * b1;
-    dst[(size_t)pyl * dw + px] = u0 + u1;
+    return u0 + u1;
+}
+
+// A fixed number of workgroups walk the 64 x 4 tiles (measured faster than one workgroup per tile: 0.63 against 0.72 ms
+// per 16384^2 plane).  MM (rsseg_ctx_collect_minmax): the plane's minimum / maximum are committed once per wave at the end
+// (one global atomic per TILE would serialise on one address).
+// (Sharing the right-hand tap with the next lane by shuffle, and four pixels per lane with one 16-byte store, were both
+// measured slower than the plain per-pixel form.)
+template <bool MM>
+__global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, int sh, int sw, float *__restrict__ dst, int dh,
+                                                 int dw, double scale_x, double scale_y, int src_row0, int dst_row0, int dh_local,
+                                                 int gx, int64_t ntiles, uint32_t *__restrict__ mm)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int px = (int)(tile % gx) * WG_X + (threadIdx.x & 63), pyl = (int)(tile / gx) * WG_Y + (threadIdx.x >> 6);
+        if (px < dw && pyl < dh_local) {
+            const float v = resize_px(src, sh, sw, scale_x, scale_y, src_row0, px, pyl + dst_row0);
+            dst[(size_t)pyl * dw + px] = v;
+            if (MM) {
+                const float z = v != v ? 0.f : v;
+                mn = fminf(mn, z);
+                mx = fmaxf(mx, z);
+            }
+        }
+    }
+    if (MM) mm_commit(mm, mn, mx);
 }
 
 static dim3 grid2d(int H, int W) { return dim3((W + WG_X - 1) / WG_X, (H + WG_Y - 1) / WG_Y); }
@@ -418,12 +439,21 @@ static int resize_rows(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw,
         return rs_fail(ctx, RSSEG_ERR_INVALID, "resize: source stripe rows [%d,%d) do not cover the tapped rows [%d,%d]", src_row0,
                        src_row0 + sh_local, need0, need1);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    RSCHK(mm_begin(ctx, 1));
     {
         prof_scope ps(ctx, "resize");
-        hipLaunchKernelGGL(k5_resize, grid2d(dh_local, dw), dim3(256), 0, ctx->stream, d_src, sh, sw, d_dst, dh, dw, scale_x, scale_y, src_row0,
-                           dst_row0, dh_local);
+        const dim3 g = grid2d(dh_local, dw);
+        const int64_t ntiles = (int64_t)g.x * g.y;
+        const dim3 pg((unsigned)std::min<int64_t>(ntiles, 8192));
+        if (ctx->mm_collect)
+            hipLaunchKernelGGL(k5_resize<true>, pg, dim3(256), 0, ctx->stream, d_src, sh, sw, d_dst, dh, dw, scale_x, scale_y, src_row0, dst_row0,
+                               dh_local, (int)g.x, ntiles, ctx->d_mm);
+        else
+            hipLaunchKernelGGL(k5_resize<false>, pg, dim3(256), 0, ctx->stream, d_src, sh, sw, d_dst, dh, dw, scale_x, scale_y, src_row0, dst_row0,
+                               dh_local, (int)g.x, ntiles, (uint32_t *)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());
+    RSCHK(mm_end(ctx, 1));
     return stream_sync(ctx);
 }
 

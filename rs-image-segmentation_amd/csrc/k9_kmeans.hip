@@ -846,7 +846,7 @@ void launch_farthest(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_
 
 template <typename T>
 int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, int k, uint32_t seed, int max_iter, double tol_in,
-               int32_t *d_labels, double *centers_out, rsseg_kmeans_info *info)
+               int32_t *d_labels, double *centers_out, rsseg_kmeans_info *info, const double *known_min, const double *known_max)
 {
     const double t_start = now_ms();
     const int KMAX = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
@@ -919,7 +919,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     scaler_t<T> sp;
     memset(&sp, 0, sizeof(sp));
     {
-        if (n > 0) {
+        const bool known = known_min != nullptr && known_max != nullptr;  // this rank's extrema came with the planes
+        if (n > 0 && !known) {
             hipLaunchKernelGGL((km_minmax<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_mm, d_mm + (size_t)nblk * F);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mm, sizeof(T) * 2 * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
@@ -929,7 +930,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         double mm[2 * RSSEG_MAX_FEATURES];
         for (int f = 0; f < F; f++) {
             T mn = (T)INFINITY, mx = (T)-INFINITY;
-            if (n > 0)
+            if (n > 0 && known) {
+                mn = (T)known_min[f];
+                mx = (T)known_max[f];
+            } else if (n > 0)
                 for (int b = 0; b < nblk; b++) {
                     mn = std::min(mn, hmn[(size_t)f * nblk + b]);
                     mx = std::max(mx, hmx[(size_t)f * nblk + b]);
@@ -1420,9 +1424,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
 
 }  // namespace
 
-extern "C" int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k,
-                                        uint32_t seed, int max_iter, double tol, int32_t *d_labels, double *centers,
-                                        rsseg_kmeans_info *info)
+static int kmeans_entry(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k, uint32_t seed, int max_iter,
+                        double tol, int32_t *d_labels, double *centers, rsseg_kmeans_info *info, const double *local_min,
+                        const double *local_max)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_planes || F < 1 || F > RSSEG_MAX_FEATURES) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: F=%d outside [1,%d]", F, RSSEG_MAX_FEATURES);
@@ -1430,10 +1434,28 @@ extern "C" int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_pla
     if (n_local < 0 || (n_local > 0 && !d_labels)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: bad n_local / labels");
     if (max_iter < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: max_iter must be >= 1");
     if (dtype != RSSEG_F32 && dtype != RSSEG_F64) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: dtype must be RSSEG_F32 or RSSEG_F64");
+    if ((local_min == nullptr) != (local_max == nullptr)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: local_min and local_max go together");
+    if (local_min && n_local > 0)
+        for (int f = 0; f < F; f++)
+            if (!(local_min[f] <= local_max[f])) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: local extrema of plane %d are not ordered numbers", f);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (info) memset(info, 0, sizeof(*info));
-    if (dtype == RSSEG_F32) return kmeans_fit<float>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info);
-    return kmeans_fit<double>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info);
+    if (dtype == RSSEG_F32) return kmeans_fit<float>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info, local_min, local_max);
+    return kmeans_fit<double>(ctx, d_planes, F, n_local, k, seed, max_iter, tol, d_labels, centers, info, local_min, local_max);
+}
+
+extern "C" int rsseg_kmeans_fit_predict(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k,
+                                        uint32_t seed, int max_iter, double tol, int32_t *d_labels, double *centers,
+                                        rsseg_kmeans_info *info)
+{
+    return kmeans_entry(ctx, d_planes, F, dtype, n_local, k, seed, max_iter, tol, d_labels, centers, info, nullptr, nullptr);
+}
+
+extern "C" int rsseg_kmeans_fit_predict_mm(rsseg_ctx *ctx, const void *const *d_planes, int F, int dtype, int64_t n_local, int k,
+                                           uint32_t seed, int max_iter, double tol, int32_t *d_labels, double *centers,
+                                           rsseg_kmeans_info *info, const double *local_min, const double *local_max)
+{
+    return kmeans_entry(ctx, d_planes, F, dtype, n_local, k, seed, max_iter, tol, d_labels, centers, info, local_min, local_max);
 }
 
 // host-only helper (no GPU): the draws sklearn takes from RandomState(seed) for k-means++ on n samples.

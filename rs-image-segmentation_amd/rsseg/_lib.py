@@ -73,6 +73,10 @@ SIGNATURES = {
     "rsseg_sobel_mag_u8": (_int, [_vp, _vp, _int, _int, _vp]),
     "rsseg_kmeans_fit_predict": (_int, [_vp, _PP, _int, _int, _i64, _int, C.c_uint32, _int, C.c_double, _vp,
                                         C.POINTER(C.c_double), C.POINTER(KMeansInfo)]),
+    "rsseg_kmeans_fit_predict_mm": (_int, [_vp, _PP, _int, _int, _i64, _int, C.c_uint32, _int, C.c_double, _vp,
+                                           C.POINTER(C.c_double), C.POINTER(KMeansInfo), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rsseg_ctx_collect_minmax": (_int, [_vp, _int]),
+    "rsseg_ctx_last_minmax": (_int, [_vp, _int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rsseg_forest_load": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8),
                                  C.POINTER(C.c_double), _int, C.POINTER(_i64), _int]),

@@ -166,6 +166,22 @@ def stack19_to_host(planes: Sequence, H: int, W: int) -> np.ndarray:
     return out
 
 
+def _with_minmax(fn):
+    """The config pipelines let the producers of the feature planes (index / upsample / projection kernels) reduce
+    each plane's minimum and maximum while they write it, so that KMeans' MinMaxScaler needs no pass of its own."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args, **kwargs):
+        ctx.collect_minmax(True)
+        try:
+            return fn(ctx, *args, **kwargs)
+        finally:
+            ctx.collect_minmax(False)
+    return wrapped
+
+
+@_with_minmax
 def config2(ctx: Context, bands: Sequence, k: int = 6):
     """BASELINE config 2: percentile normalisation + 7 spectral indices + KMeans(k)."""
     lohi = band_lohi(ctx, bands[:5])
@@ -175,6 +191,7 @@ def config2(ctx: Context, bands: Sequence, k: int = 6):
     return labels, meta, planes
 
 
+@_with_minmax
 def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3,
             n_global: Optional[int] = None, overlap: bool = False):
     """BASELINE config 3: 7 indices + 5 GLCM properties (window 7, 4 angles) + PCA(3) -> 15 float32
@@ -240,6 +257,7 @@ def glcm_halo_rows(H: int, r0: int, r1: int, win: int, step: int) -> Tuple[int, 
     return j0, j1, j0 * step, j1 * step + win
 
 
+@_with_minmax
 def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: int, r1: int, i0: int, k: int = 8,
                     glcm_window=7, glcm_step=1, n_pca=3):
     """BASELINE config 3/4 on ONE H x W raster sharded by rows: this rank owns rows [r0, r1) (`bands`: its

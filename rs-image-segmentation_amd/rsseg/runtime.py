@@ -154,6 +154,24 @@ class Context:
             arr[i] = None if t is None else t.data_ptr()
         return arr
 
+    # ---- extrema of produced planes -------------------------------------------------------------
+    def collect_minmax(self, on: bool = True):
+        """While on, spectral_indices / resize_bilinear(_rows) / pca_fit_transform tag every plane they return with
+        its (min, max) — attribute `_rsseg_minmax`, NaN counted as 0 — and kmeans_fit_predict skips its MinMaxScaler
+        pass when all its planes carry the tag.  The tag describes the plane as produced: do not modify a tagged plane."""
+        self._chk(self.lib.rsseg_ctx_collect_minmax(self.h, int(on)))
+        self._collect = bool(on)
+
+    def _tag_minmax(self, tensors: Sequence):
+        if not getattr(self, "_collect", False):
+            return
+        for i, t in enumerate(tensors):
+            if t is None:
+                continue
+            mn, mx = C.c_double(0), C.c_double(0)
+            self._chk(self.lib.rsseg_ctx_last_minmax(self.h, i, C.byref(mn), C.byref(mx)))
+            t._rsseg_minmax = (mn.value, mx.value)
+
     # ---- profiling ---------------------------------------------------------------------------
     def prof_enable(self, on=True):
         self._chk(self.lib.rsseg_prof_enable(self.h, int(on)))
@@ -204,6 +222,7 @@ class Context:
         if lohi is not None:
             lh = (C.c_float * 10)(*[float(v) for v in np.asarray(lohi, np.float32).reshape(-1)])
         self._chk(self.lib.rsseg_spectral_indices_f32(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms)))
+        self._tag_minmax(outs)
         return outs, norms
 
     def quantize_u8(self, plane, mult: float):
@@ -236,6 +255,7 @@ class Context:
         self._chk(self.lib.rsseg_pca_fit_transform_f32(self.h, self._pp(bands), nb, n, cptr, sptr, n_components,
                                                        self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
                                                        mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        self._tag_minmax(outs)
         return outs, comp, ratio, mean, ev
 
     # ---- K4..K8 --------------------------------------------------------------------------------
@@ -251,6 +271,7 @@ class Context:
         dst = self.empty(dh * dw, torch.float32)
         self._chk(self.lib.rsseg_resize_bilinear_f32(self.h, C.c_void_p(src.data_ptr()), sh, sw, C.c_void_p(dst.data_ptr()),
                                                      dh, dw))
+        self._tag_minmax([dst])
         return dst
 
     def resize_bilinear_rows(self, src, sh_local: int, sw: int, src_row0: int, sh: int, dh_local: int, dw: int, dst_row0: int, dh: int):
@@ -258,6 +279,7 @@ class Context:
         dst = self.empty(dh_local * dw, torch.float32)
         self._chk(self.lib.rsseg_resize_bilinear_rows_f32(self.h, C.c_void_p(src.data_ptr()), sh_local, sw, src_row0, sh,
                                                           C.c_void_p(dst.data_ptr()), dh_local, dw, dst_row0, dh))
+        self._tag_minmax([dst])
         return dst
 
     def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False):
@@ -314,9 +336,17 @@ class Context:
         labels = self.empty(max(n, 1), torch.int32)
         centers = np.zeros((n_clusters, F), np.float64)
         info = L.KMeansInfo()
-        self._chk(self.lib.rsseg_kmeans_fit_predict(self.h, self._pp(planes), F, L.F32 if dt == torch.float32 else L.F64, n,
-                                                    n_clusters, seed, max_iter, tol, C.c_void_p(labels.data_ptr()),
-                                                    centers.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info)))
+        tags = [getattr(p, "_rsseg_minmax", None) for p in planes]
+        if dt == torch.float32 and n > 0 and all(t is not None for t in tags):
+            lmin = (C.c_double * F)(*[t[0] for t in tags])
+            lmax = (C.c_double * F)(*[t[1] for t in tags])
+            self._chk(self.lib.rsseg_kmeans_fit_predict_mm(self.h, self._pp(planes), F, L.F32, n, n_clusters, seed, max_iter, tol,
+                                                           C.c_void_p(labels.data_ptr()), centers.ctypes.data_as(C.POINTER(C.c_double)),
+                                                           C.byref(info), lmin, lmax))
+        else:
+            self._chk(self.lib.rsseg_kmeans_fit_predict(self.h, self._pp(planes), F, L.F32 if dt == torch.float32 else L.F64, n,
+                                                        n_clusters, seed, max_iter, tol, C.c_void_p(labels.data_ptr()),
+                                                        centers.ctypes.data_as(C.POINTER(C.c_double)), C.byref(info)))
         meta = dict(n_iter=info.n_iter, tol=info.tol, relocated=info.relocated,
                     scale=np.array(info.scale[:F]), min=np.array(info.min[:F]), mean=np.array(info.mean[:F]),
                     init_indices=np.array(info.init_indices[:n_clusters]), ms_init=info.ms_init, ms_lloyd=info.ms_lloyd,

@@ -365,6 +365,35 @@ def test_kmeans_errors(ctx):
         ctx.kmeans_fit_predict([x] * 40, 2)  # too many features
 
 
+def test_producer_minmax_tags_and_kmeans_shortcut(ctx, crop, oracle):
+    """Planes written while rsseg_ctx_collect_minmax is on carry their exact (min, max), NaN counted as 0, and KMeans
+    given such planes (no MinMaxScaler pass) returns what it returns for untagged copies."""
+    import torch
+    from rsseg import pipeline as P
+    bands = [dev(ctx, b) for b in crop["bands"]]
+    ctx.collect_minmax(True)
+    try:
+        lohi = P.band_lohi(ctx, bands[:5])
+        idx, _ = P.spectral_indices(ctx, bands, lohi)
+        planes = [idx[n] for n in P.INDEX_NAMES]
+        up = ctx.resize_bilinear(planes[0][:90 * 96].contiguous(), 90, 96, 96, 96)
+        normd = [ctx.normalize(b, 0.0, 255.0) for b in bands]
+        pcs, *_ = ctx.pca_fit_transform(normd, None, None, 3)
+    finally:
+        ctx.collect_minmax(False)
+    for t in planes + [up] + list(pcs):
+        mn, mx = t._rsseg_minmax
+        z = torch.nan_to_num(t, nan=0.0)
+        assert mn == float(z.min()) and mx == float(z.max())
+    feats = planes + list(pcs)
+    lab_a, meta_a = ctx.kmeans_fit_predict(feats, 6)
+    lab_b, meta_b = ctx.kmeans_fit_predict([t.clone() for t in feats], 6)   # clones carry no tag: full scaler pass
+    assert torch.equal(lab_a, lab_b) and meta_a["n_iter"] == meta_b["n_iter"]
+    assert np.array_equal(meta_a["centers"], meta_b["centers"]) and np.array_equal(meta_a["scale"], meta_b["scale"])
+    # a plane produced with collection off is not tagged
+    assert not hasattr(ctx.resize_bilinear(planes[0][:90 * 96].contiguous(), 90, 96, 96, 96), "_rsseg_minmax")
+
+
 def test_kmeans_large_properties(ctx, oracle):
     """2048 x 2048 synthetic raster: beyond what the CPU oracle finishes quickly, so check
     size-independent properties: determinism, every label is the argmin of its distance row, the centres
