@@ -130,6 +130,12 @@ int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int
                                 const float *center, const double *scale, int n_components,
                                 float *const *d_out, float *components, float *explained_variance_ratio,
                                 float *mean, float *explained_variance);
+/* The same on RAW bands: each value first goes through robust_normalize with lohi[2*b], lohi[2*b+1] (np.percentile 2 /
+ * 98 of band b) — the arithmetic of rsseg_normalize_f32 — so the normalised planes need not exist in memory. */
+int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi,
+                                    const float *center, const double *scale, int n_components, float *const *d_out,
+                                    float *components, float *explained_variance_ratio, float *mean,
+                                    float *explained_variance);
 
 /* ---- K4/K5: GLCM texture + bilinear upsample ------------------------------------------- */
 /* calculate_glcm_features (indices.py:248-318), window loop: d_q is the quantised uint8 plane
@@ -141,6 +147,9 @@ int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int levels, 
                   float *const *d_props);
 /* float32 plane in [0,1] -> uint8 by truncation of x*mult (indices.py:268, 415, 458). */
 int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, uint8_t *d_q);
+/* robust_normalize(x) with the given percentiles, then the truncation of rsseg_quantize_u8, in one pass (the texture
+ * functions re-normalise the band they receive before quantising it, indices.py:265-268, 412-415). */
+int rsseg_normalize_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, float mult, uint8_t *d_q);
 /* uint8 plane -> float32 of (uint8 / 255.0 in float64): the value sklearn sees for the morphological members
  * (features[...] = gradient / 255.0, indices.py:436-440; float32 cast sklearn/ensemble/_forest.py:640). */
 int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out);

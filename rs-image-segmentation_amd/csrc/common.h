@@ -91,10 +91,25 @@ struct prof_scope {
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// float32 (hi - lo + 1e-10) of robust_normalize (indices.py:44)
+static inline float norm_den(float lo, float hi)
+{
+    volatile float d = hi - lo;
+    volatile float e = d + 1e-10f;
+    return e;
+}
 
 #ifdef __HIPCC__
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// robust_normalize of one value: np.clip keeps NaN; (clipped - lo) / (hi - lo + 1e-10), float32 (indices.py:41-44)
+__device__ __forceinline__ float norm1(float x, float lo, float hi, float den)
+{
+    float c = x < lo ? lo : x;
+    c = c > hi ? hi : c;
+    return (c - lo) / den;
+}
 
 template <typename V>
 __device__ __forceinline__ V wave_sum(V v)

@@ -7,13 +7,6 @@
 
 #define K2_THREADS 256
 
-__device__ __forceinline__ float norm1(float x, float lo, float hi, float den)
-{
-    // np.clip keeps NaN; (clipped - lo) / (hi - lo + 1e-10)
-    float c = x < lo ? lo : x;
-    c = c > hi ? hi : c;
-    return (c - lo) / den;
-}
 __device__ __forceinline__ float clip11(float v)
 {
     v = v < -1.0f ? -1.0f : v;
@@ -144,19 +137,27 @@ __global__ __launch_bounds__(K2_THREADS) void k2_normalize(const float *__restri
     if (t < n) y[t] = norm1(x[t], lo, hi, den);
 }
 
-__global__ __launch_bounds__(K2_THREADS) void k2_quantize(const float *__restrict__ x, uint8_t *__restrict__ q, int64_t n, float mult)
+// NORM: robust_normalize(x) with the given percentiles first (the texture functions re-normalise the band they are
+// handed, indices.py:265, 412, 455), then the truncation — one pass, no float32 intermediate plane
+template <bool NORM>
+__global__ __launch_bounds__(K2_THREADS) void k2_quantize(const float *__restrict__ x, uint8_t *__restrict__ q, int64_t n, float mult,
+                                                         float lo, float hi, float den)
 {
     // (x * mult).astype(np.uint8): truncation toward zero of a value in [0, mult]
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
         float4 v = reinterpret_cast<const float4 *>(x)[i];
+        if (NORM) {
+            v.x = norm1(v.x, lo, hi, den); v.y = norm1(v.y, lo, hi, den);
+            v.z = norm1(v.z, lo, hi, den); v.w = norm1(v.w, lo, hi, den);
+        }
         uchar4 o;
         o.x = (uint8_t)(int)(v.x * mult); o.y = (uint8_t)(int)(v.y * mult);
         o.z = (uint8_t)(int)(v.z * mult); o.w = (uint8_t)(int)(v.w * mult);
         reinterpret_cast<uchar4 *>(q)[i] = o;
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * K2_THREADS + threadIdx.x;
-    if (t < n) q[t] = (uint8_t)(int)(x[t] * mult);
+    if (t < n) q[t] = (uint8_t)(int)((NORM ? norm1(x[t], lo, hi, den) : x[t]) * mult);
 }
 
 __global__ __launch_bounds__(K2_THREADS) void k2_u8_unit(const uint8_t *__restrict__ q, float *__restrict__ y, int64_t n)
@@ -169,13 +170,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2_u8_unit(const uint8_t *__restri
 static int stream_grid(int64_t n4)
 {
     return (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n4, K2_THREADS)));
-}
-
-static inline float norm_den(float lo, float hi)
-{
-    volatile float d = hi - lo;
-    volatile float e = d + 1e-10f;
-    return e;
 }
 
 extern "C" int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, float *d_out)
@@ -235,7 +229,22 @@ extern "C" int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, fl
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         prof_scope ps(ctx, "indices");
-        hipLaunchKernelGGL(k2_quantize, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult);
+        hipLaunchKernelGGL(k2_quantize<false>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult, 0.f, 1.f, 1.f);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_normalize_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, float mult, uint8_t *d_q)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_q || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize_quantize: bad arguments");
+    if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 3)) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize_quantize: unaligned plane");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "indices");
+        hipLaunchKernelGGL(k2_quantize<true>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult, lo, hi,
+                           norm_den(lo, hi));
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

@@ -24,6 +24,8 @@ struct pca_args {
     double scale[PCA_MAXB];
     double rinv[PCA_MAXB];  // RN(1 / scale)
     int slow_div;           // a scale whose reciprocal trick is not provably exact: use the IEEE division
+    float nlo[PCA_MAXB], nhi[PCA_MAXB], nden[PCA_MAXB];  // raw bands: robust_normalize(v) with these percentiles first
+    int normalise;
     int nb;
     int scaled;
     double fx_scale;  // 2^Q used for the fixed-point accumulation of x and x*x
@@ -31,6 +33,7 @@ struct pca_args {
 
 __device__ __forceinline__ float pca_x(const pca_args &a, int b, float v)
 {
+    if (a.normalise) v = norm1(v, a.nlo[b], a.nhi[b], a.nden[b]);
     if (!a.scaled) return v;
     const float d = v - a.center[b];
     if (a.slow_div) return (float)((double)d / a.scale[b]);
@@ -227,10 +230,32 @@ static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][
     for (int i = 0; i < n; i++) w[i] = A[i][i];
 }
 
+static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi, const float *center,
+                    const double *scale, int n_components, float *const *d_out, float *components, float *explained_variance_ratio,
+                    float *mean, float *explained_variance);
+
 extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local,
                                            const float *center, const double *scale, int n_components, float *const *d_out,
                                            float *components, float *explained_variance_ratio, float *mean,
                                            float *explained_variance)
+{
+    return pca_core(ctx, d_bands, nb, n_local, nullptr, center, scale, n_components, d_out, components, explained_variance_ratio, mean,
+                    explained_variance);
+}
+
+extern "C" int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi,
+                                               const float *center, const double *scale, int n_components, float *const *d_out,
+                                               float *components, float *explained_variance_ratio, float *mean,
+                                               float *explained_variance)
+{
+    if (ctx && !lohi) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_raw: lohi is required");
+    return pca_core(ctx, d_bands, nb, n_local, lohi, center, scale, n_components, d_out, components, explained_variance_ratio, mean,
+                    explained_variance);
+}
+
+static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi, const float *center,
+                    const double *scale, int n_components, float *const *d_out, float *components, float *explained_variance_ratio,
+                    float *mean, float *explained_variance)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_bands || nb < 1 || nb > PCA_MAXB || n_components < 1 || n_components > nb || n_local < 0)
@@ -240,11 +265,17 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
     pca_args a;
     memset(&a, 0, sizeof(a));
     a.nb = nb;
+    a.normalise = lohi != nullptr;
     a.scaled = center != nullptr;
     for (int b = 0; b < nb; b++) {
         if (!d_bands[b] || ((uintptr_t)d_bands[b] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: band %d null or unaligned", b);
         a.band[b] = d_bands[b];
         a.center[b] = center ? center[b] : 0.f;
+        if (lohi) {
+            a.nlo[b] = lohi[2 * b];
+            a.nhi[b] = lohi[2 * b + 1];
+            a.nden[b] = norm_den(a.nlo[b], a.nhi[b]);
+        }
         a.scale[b] = scale ? scale[b] : 1.0;
         a.rinv[b] = 1.0 / a.scale[b];
         uint64_t sb;

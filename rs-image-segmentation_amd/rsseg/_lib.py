@@ -59,6 +59,10 @@ SIGNATURES = {
     "rsseg_pca_fit_transform_f32": (_int, [_vp, _PP, _int, _i64, C.POINTER(C.c_float), C.POINTER(C.c_double), _int, _PP,
                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                            C.POINTER(C.c_float)]),
+    "rsseg_pca_fit_transform_raw_f32": (_int, [_vp, _PP, _int, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                               _int, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float)]),
+    "rsseg_normalize_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp]),
     "rsseg_glcm_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _PP]),
     "rsseg_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, _vp]),
     "rsseg_u8_to_unit_f32": (_int, [_vp, _vp, _i64, _vp]),

@@ -91,11 +91,14 @@ def spectral_indices(ctx: Context, bands: Sequence, lohi: Optional[np.ndarray], 
 
 
 def pca(ctx: Context, norm_bands: Sequence, n_components: Optional[int] = None, use_robust_scaling: bool = True,
-        n_global: Optional[int] = None, stats=None):
+        n_global: Optional[int] = None, stats=None, lohi=None):
     """perform_pca (indices.py:205-246) on normalised band planes.  `stats` (optional): precomputed
-    [(center, scale)] per band from band_quantile_bundle."""
+    [(center, scale)] per band from band_quantile_bundle.  `lohi` (optional, with `stats`): the planes are the RAW bands
+    and are robust-normalised with these percentiles inside the PCA kernels (no normalised planes in memory)."""
     nb = len(norm_bands)
     nc = nb if n_components is None else n_components
+    if lohi is not None and use_robust_scaling and stats is None:
+        raise ValueError("pca: raw bands (lohi) need the RobustScaler statistics of the normalised bands (stats)")
     if use_robust_scaling:
         if stats is None:
             stats = [robust_scaler_stats(ctx, b, n_global) for b in norm_bands]
@@ -103,7 +106,7 @@ def pca(ctx: Context, norm_bands: Sequence, n_components: Optional[int] = None, 
         scale = np.array([s[1] for s in stats], np.float64)
     else:
         center = scale = None
-    outs, comp, ratio, mean, ev = ctx.pca_fit_transform(list(norm_bands), center, scale, nc)
+    outs, comp, ratio, mean, ev = ctx.pca_fit_transform(list(norm_bands), center, scale, nc, lohi)
     return outs, ratio, dict(components=comp, mean=mean, explained_variance=ev, center=center, scale=scale)
 
 
@@ -114,9 +117,13 @@ def renormalize(ctx: Context, plane, n_global: Optional[int] = None):
     return ctx.normalize(plane, float(lo), float(hi))
 
 
-def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size=21, step_size=21, upsample=True):
-    """calculate_glcm_features (indices.py:248-318) on an already re-normalised band."""
-    q = ctx.quantize_u8(nir_norm, float(levels - 1))
+def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size=21, step_size=21, upsample=True, renorm=None):
+    """calculate_glcm_features (indices.py:248-318) on an already re-normalised band, or — renorm=(lo, hi) — on the band
+    as the function receives it, re-normalised with its percentiles and quantised in one pass."""
+    if renorm is None:
+        q = ctx.quantize_u8(nir_norm, float(levels - 1))
+    else:
+        q = ctx.normalize_quantize_u8(nir_norm, float(renorm[0]), float(renorm[1]), float(levels - 1))
     small, (oh, ow) = ctx.glcm(q, H, W, levels, window_size, step_size)
     if not upsample:
         return dict(zip(GLCM_NAMES, small)), (oh, ow)
@@ -201,12 +208,31 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     (profiles/r01_overlap_note.md): the GLCM kernel fills every CU and slows down by what the other stream
     executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default."""
     NIR = 3
-    if overlap:   # the NIR band's statistics first, so that its texture chain can start beside the rest
-        qn = band_quantile_bundle(ctx, bands[NIR], n_global)
-        qb = None
-    else:
+    if not overlap:
+        # one grouped select, then: indices (+ the normalised NIR band only), texture chain on the normalised NIR band
+        # re-normalised and quantised in one pass, PCA straight from the RAW bands (normalisation inside its kernels)
         qb = band_quantile_bundles(ctx, bands, n_global)
-        qn = qb[NIR]
+        lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+        fused = all(q["center"] is not None for q in qb)
+        want = tuple(i == NIR for i in range(5)) if fused else (True,) * 5
+        idx, norms = spectral_indices(ctx, bands, lohi, want_norm=want)
+        if fused:
+            lo2, hi2 = qb[NIR]["lo2"], qb[NIR]["hi2"]
+        else:
+            lo2, hi2 = band_percentiles(ctx, norms[NIR], (2, 98), n_global)
+        glcm, _ = glcm_features(ctx, norms[NIR], H, W, 32, glcm_window, glcm_step, renorm=(lo2, hi2))
+        if fused:
+            pcs, ratio, model = pca(ctx, bands, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
+        else:  # a band with NaNs: separate selects on the normalised planes
+            norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+            pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, None)
+            del norm_all
+        del norms
+        planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
+        labels, meta = ctx.kmeans_fit_predict(planes, k)
+        return labels, meta, planes
+    # overlap: the NIR band's statistics first, so that its texture chain can start beside the rest
+    qn = band_quantile_bundle(ctx, bands[NIR], n_global)
     fused = qn["center"] is not None
     nir_norm = ctx.normalize(bands[NIR], float(qn["lo"]), float(qn["hi"]))
     if fused:
@@ -214,21 +240,18 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     else:
         lo2, hi2 = band_percentiles(ctx, nir_norm, (2, 98), n_global)
     nir2 = ctx.normalize(nir_norm, float(lo2), float(hi2))
-    g = ctx.aux() if overlap else ctx
-    if overlap:
-        g.torch_stream.wait_stream(ctx.torch_stream)
+    g = ctx.aux()
+    g.torch_stream.wait_stream(ctx.torch_stream)
     glcm, _ = glcm_features(g, nir2, H, W, 32, glcm_window, glcm_step)   # asynchronous on the aux stream
-    if qb is None:
-        rest = band_quantile_bundles(ctx, [b for i, b in enumerate(bands) if i != NIR], n_global)
-        qb = rest[:NIR] + [qn] + rest[NIR:]
+    rest = band_quantile_bundles(ctx, [b for i, b in enumerate(bands) if i != NIR], n_global)
+    qb = rest[:NIR] + [qn] + rest[NIR:]
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
     norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
     stats = [(q["center"], q["scale"]) for q in qb] if all(q["center"] is not None for q in qb) else None
     pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, stats)
     del norm_all, norms
-    if overlap:
-        g.sync()
+    g.sync()
     planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes
@@ -267,19 +290,21 @@ def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: 
     n_global = H * W
     qb = band_quantile_bundles(ctx, bands, n_global)
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
-    idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
-    norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
     fused = all(q["center"] is not None for q in qb)
-    pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
-    if fused:
+    if fused:   # PCA straight from the raw stripes; no normalised planes are written
+        idx, _ = spectral_indices(ctx, bands, lohi)
+        pcs, ratio, model = pca(ctx, bands, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
         lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
     else:
+        idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+        norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+        pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, None)
         lo2, hi2 = band_percentiles(ctx, norm_all[3], (2, 98), n_global)
-    del norm_all, norms
+        del norm_all, norms
     ext_rows = nir_ext.numel() // W
     nir_n = ctx.normalize(nir_ext, float(lohi[3, 0]), float(lohi[3, 1]))
-    nir2 = ctx.normalize(nir_n, float(lo2), float(hi2), out=nir_n)
-    q = ctx.quantize_u8(nir2, 31.0)
+    q = ctx.normalize_quantize_u8(nir_n, float(lo2), float(hi2), 31.0)
+    del nir_n
     j0, j1, need_i0, need_i1 = glcm_halo_rows(H, r0, r1, glcm_window, glcm_step)
     if need_i0 < i0 or need_i1 > i0 + ext_rows or (need_i0 - i0) % glcm_step:
         raise ValueError(f"nir_ext rows [{i0},{i0 + ext_rows}) do not cover the texture rows [{need_i0},{need_i1})")

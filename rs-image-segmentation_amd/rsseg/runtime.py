@@ -232,6 +232,14 @@ class Context:
                                              C.c_void_p(q.data_ptr())))
         return q
 
+    def normalize_quantize_u8(self, plane, lo: float, hi: float, mult: float):
+        """trunc(robust_normalize(plane; lo, hi) * mult) as uint8 in one pass."""
+        torch = _torch()
+        q = self.empty(plane.numel(), torch.uint8)
+        self._chk(self.lib.rsseg_normalize_quantize_u8(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo), C.c_float(hi),
+                                                       C.c_float(mult), C.c_void_p(q.data_ptr())))
+        return q
+
     def u8_to_unit(self, q):
         torch = _torch()
         out = self.empty(q.numel(), torch.float32)
@@ -240,7 +248,8 @@ class Context:
 
     # ---- K3 ------------------------------------------------------------------------------------
     def pca_fit_transform(self, bands: Sequence, center: Optional[np.ndarray], scale: Optional[np.ndarray],
-                          n_components: int):
+                          n_components: int, lohi: Optional[np.ndarray] = None):
+        """lohi (nb x 2 float32, optional): the bands are RAW and are robust-normalised with these percentiles on the fly."""
         torch = _torch()
         nb, n = len(bands), bands[0].numel()
         outs = [self.empty(n, torch.float32) for _ in range(n_components)]
@@ -252,9 +261,17 @@ class Context:
         cptr = None if center is None else np.ascontiguousarray(center, np.float32).ctypes.data_as(fp)
         sc64 = None if scale is None else np.ascontiguousarray(scale, np.float64)
         sptr = None if sc64 is None else sc64.ctypes.data_as(C.POINTER(C.c_double))
-        self._chk(self.lib.rsseg_pca_fit_transform_f32(self.h, self._pp(bands), nb, n, cptr, sptr, n_components,
-                                                       self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
-                                                       mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        if lohi is None:
+            self._chk(self.lib.rsseg_pca_fit_transform_f32(self.h, self._pp(bands), nb, n, cptr, sptr, n_components,
+                                                           self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
+                                                           mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        else:
+            lh = np.ascontiguousarray(lohi, np.float32).reshape(-1)
+            if lh.size != 2 * nb:
+                raise ValueError("pca_fit_transform: lohi must hold (lo, hi) for every band")
+            self._chk(self.lib.rsseg_pca_fit_transform_raw_f32(self.h, self._pp(bands), nb, n, lh.ctypes.data_as(fp), cptr, sptr, n_components,
+                                                               self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
+                                                               mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
         self._tag_minmax(outs)
         return outs, comp, ratio, mean, ev
 

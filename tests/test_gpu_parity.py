@@ -735,3 +735,29 @@ def test_full_size_16384_window_ops_and_forest(ctx, oracle, golden_dir):
     assert np.array_equal(out[-tail:].cpu().numpy(), want)
     head = oracle.rf_predict_planes(f, [pl[:tail].cpu().numpy() for pl in planes])
     assert np.array_equal(out[:tail].cpu().numpy(), head)
+
+
+def test_raw_band_pca_and_fused_quantise_equal_two_step_forms(ctx, crop, oracle):
+    """rsseg_pca_fit_transform_raw_f32 on raw bands + percentiles == rsseg_pca_fit_transform_f32 on the normalised planes,
+    and rsseg_normalize_quantize_u8 == normalise then quantise (bit for bit)."""
+    import torch
+    from rsseg import pipeline as P
+    bands = [dev(ctx, b) for b in crop["bands"]]
+    qb = P.band_quantile_bundles(ctx, bands)
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+    stats = [(q["center"], q["scale"]) for q in qb]
+    normd = [ctx.normalize(b, float(lohi[i, 0]), float(lohi[i, 1])) for i, b in enumerate(bands)]
+    a, ra, ma = P.pca(ctx, normd, 3, True, None, stats)
+    b, rb, mb = P.pca(ctx, bands, 3, True, None, stats, lohi=lohi)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert np.array_equal(ra, rb) and np.array_equal(ma["components"], mb["components"])
+    c, rc, _ = P.pca(ctx, normd, 7, False)
+    d, rd, _ = P.pca(ctx, bands, 7, False, lohi=lohi)
+    assert all(torch.equal(x, y) for x, y in zip(c, d)) and np.array_equal(rc, rd)
+    lo2, hi2 = float(qb[3]["lo2"]), float(qb[3]["hi2"])
+    two = ctx.quantize_u8(ctx.normalize(normd[3], lo2, hi2), 31.0)
+    one = ctx.normalize_quantize_u8(normd[3], lo2, hi2, 31.0)
+    assert torch.equal(one, two)
+    with pytest.raises(ValueError):
+        P.pca(ctx, bands, 3, True, lohi=lohi)  # raw bands need the precomputed RobustScaler statistics
