@@ -64,14 +64,14 @@ def algorithmic_bytes_per_px(family, F, glcm_step, k=8):
         # k passes: first centre reads F planes; round 1 also writes the closest plane; later rounds read + write it
         "kpp": (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1),
         "select": 4,                                   # one radix pass over one float32 plane
-        "indices": 20 + 28,                            # 5 bands in, 7 indices out
+        "indices": 20 + 28 + 4,                        # 5 bands in, 7 indices + the normalised NIR band out
         "gram": 28, "project": 28 + 12, "resize": 8, "box": 8, "stencil": 8, "forest": 4 * F + 8,
     }[family]
 
 
 # kernel family -> name of its dominant kernel in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
 PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7, 3>",
-              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices", "gram": "k3_gram<7>", "project": "k3_project<7>", "resize": "k5_resize"}
+              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>", "resize": "k5_resize<true>"}
 
 
 def pmc_traffic_bytes(family, px):
