@@ -190,10 +190,10 @@ int mm_begin(rsseg_ctx *ctx, int nplanes)
 {
     ctx->mm_count = 0;
     if (!ctx->mm_collect) return RSSEG_OK;
-    uint32_t init[2 * RSSEG_MM_PLANES];
-    for (int i = 0; i < RSSEG_MM_PLANES; i++) { init[2 * i] = 0xffffffffu; init[2 * i + 1] = 0u; }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // init lives on this stack frame
+    // slot layout {min key, max key} per plane: 0xffffffff / 0 via two strided fills would need a kernel; one 2-D memset
+    // does it without touching host memory (no synchronisation): bytes 0..3 of each 8-byte slot = 0xff, 4..7 = 0x00
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_mm, 0, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES, ctx->stream));
+    HIPCHK(ctx, hipMemset2DAsync(ctx->d_mm, 8, 0xff, 4, RSSEG_MM_PLANES, ctx->stream));
     (void)nplanes;
     return RSSEG_OK;
 }

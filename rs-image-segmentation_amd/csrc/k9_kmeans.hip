@@ -323,34 +323,122 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
     }
 }
 
-// The current closest-distance values of ONE chunk (the one a sample falls into), i.e. what the next km_kpp round
-// will store for it: out[i] = with_old ? min(closest[c0+i], d2(pending, x)) : d2(pending, x).  Same operation
-// sequence as km_kpp, so the same bits.
+// Sampling step of a k-means++ round on the device (np.searchsorted(stable_cumsum(closest), r), _kmeans.py:243-246, for the
+// chunk the host has already located from the chunk sums).  One workgroup per candidate:
+//   mode 1: km_kpp_chunkq re-derives the current closest-distance values of the chunk [c0, c0 + cn) — what the next km_kpp
+//           round will store for it: with_old ? min(closest, d2(pending, x)) : d2(pending, x), same operation sequence as
+//           km_kpp, so the same bits — as fixed-point integers; km_kpp_sample finds the first pixel whose running sum
+//           reaches `rem` (the target minus the sum of everything before the chunk) with a two-level search;
+//   mode 2: the pixel is given (np.clip of an index past the end);   mode 0: another rank owns this candidate.
+// Writes out[l] = {global index as double, the F scaled+centred values of that pixel as double}; one device-to-host copy
+// then serves all candidates of the round (instead of a chunk copy and a row copy per candidate).
+struct kpp_sample_args {
+    int64_t c0[KPP_MAXL], cn[KPP_MAXL], direct[KPP_MAXL];
+    unsigned long long rem[KPP_MAXL];
+    int mode[KPP_MAXL];
+    int with_old;
+    int64_t offset;
+};
+// step 1 (grid: chunk / 256 x L): the fixed-point images of the current closest distances of candidate l's chunk
 template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void km_kpp_chunk(planes_t pl, int F, int64_t c0, int64_t cn, const scaler_t<T> *__restrict__ sp,
-                                                           const double *__restrict__ candT, const double *__restrict__ cc,
-                                                           const T *__restrict__ closest, int with_old, T *__restrict__ out)
+__global__ __launch_bounds__(KM_THREADS) void km_kpp_chunkq(planes_t pl, int F, const scaler_t<T> *__restrict__ sp,
+                                                            const double *__restrict__ candT, const double *__restrict__ cc,
+                                                            const T *__restrict__ closest, kpp_sample_args a,
+                                                            unsigned long long *__restrict__ qv)
 {
+    const int l = blockIdx.y;
+    if (a.mode[l] != 1) return;
+    const int64_t c0 = a.c0[l], cn = a.cn[l];
+    const int64_t i = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
+    if (i >= cn) return;
     const double ccp = cc[KPP_MAXL];
-    for (int64_t i = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x; i < cn; i += (int64_t)gridDim.x * KM_THREADS) {
-        double yy = 0.0, dotp = 0.0;
-        for (int f = 0; f < F; f++) {
-            const T xv = reinterpret_cast<const T *>(pl.p[f])[c0 + i];
-            const T yt = scaled<T>(xv, sp->scale[f], sp->minv[f]) - sp->mean[f];
-            const double y = (double)yt;
-            yy = fma(y, y, yy);
-            dotp = fma(candT[f * KPP_STRIDE + KPP_MAXL], y, dotp);
+    double yy = 0.0, dotp = 0.0;
+    for (int f = 0; f < F; f++) {
+        const T xv = reinterpret_cast<const T *>(pl.p[f])[c0 + i];
+        const T yt = scaled<T>(xv, sp->scale[f], sp->minv[f]) - sp->mean[f];
+        const double y = (double)yt;
+        yy = fma(y, y, yy);
+        dotp = fma(candT[f * KPP_STRIDE + KPP_MAXL], y, dotp);
+    }
+    double d = -2.0 * dotp;
+    d = d + ccp;
+    d = d + yy;
+    T dt = (T)d;
+    dt = dt > (T)0 ? dt : (T)0;
+    if (a.with_old) {
+        const T c = closest[c0 + i];
+        dt = c < dt ? c : dt;
+    }
+    qv[(size_t)l * km_chunk<T>() + i] = (unsigned long long)to_fixed40((double)dt);
+}
+
+// step 2 (one workgroup per candidate): two-level search over the exact prefix sums, then the row of the pixel found
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void km_kpp_sample(planes_t pl, int F, const scaler_t<T> *__restrict__ sp,
+                                                            const unsigned long long *__restrict__ qv, kpp_sample_args a,
+                                                            double *__restrict__ out)
+{
+    const int l = blockIdx.x;
+    double *o = out + (size_t)l * (1 + RSSEG_MAX_FEATURES);
+    if (a.mode[l] == 0) return;
+    constexpr int ROWS = (int)(km_chunk<T>() / KM_THREADS);  // rows of 256 consecutive pixels
+    __shared__ unsigned long long rowsum[ROWS];
+    __shared__ unsigned long long rowq[KM_THREADS];
+    __shared__ long long s_li;
+    __shared__ int s_row;
+    __shared__ unsigned long long s_rem;
+    const int64_t c0 = a.c0[l], cn = a.cn[l];
+    if (a.mode[l] == 1) {
+        const unsigned long long *q = qv + (size_t)l * km_chunk<T>();
+        for (int r = threadIdx.x; r < ROWS; r += KM_THREADS) rowsum[r] = 0ull;
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < ROWS; r++) {
+            const int64_t i = (int64_t)r * KM_THREADS + threadIdx.x;
+            unsigned long long v = i < cn ? q[i] : 0ull;
+            v = wave_sum(v);
+            if (lane_id() == 0 && v) atomicAdd(&rowsum[r], v);
         }
-        double d = -2.0 * dotp;
-        d = d + ccp;
-        d = d + yy;
-        T dt = (T)d;
-        dt = dt > (T)0 ? dt : (T)0;
-        if (with_old) {
-            const T c = closest[c0 + i];
-            dt = c < dt ? c : dt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long run = 0;
+            int r = 0;
+            for (; r < ROWS; r++) {
+                if (run + rowsum[r] >= a.rem[l]) break;
+                run += rowsum[r];
+            }
+            s_row = r;                 // ROWS: never reached (cannot happen: the chunk sum reaches the target)
+            s_rem = a.rem[l] - run;    // what the pixels of row r still have to cover
         }
-        out[i] = dt;
+        __syncthreads();
+        if (s_row >= ROWS) {
+            if (threadIdx.x == 0) s_li = cn - 1;
+        } else {
+            const int64_t i = (int64_t)s_row * KM_THREADS + threadIdx.x;
+            rowq[threadIdx.x] = i < cn ? q[i] : 0ull;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long run = 0;
+                int64_t li = cn - 1;
+                for (int t = 0; t < KM_THREADS; t++) {
+                    if ((int64_t)s_row * KM_THREADS + t >= cn) break;
+                    run += rowq[t];
+                    if (run >= s_rem) { li = (int64_t)s_row * KM_THREADS + t; break; }
+                }
+                s_li = li;
+            }
+        }
+        __syncthreads();
+    } else {
+        if (threadIdx.x == 0) s_li = a.direct[l] - c0;
+        __syncthreads();
+    }
+    const int64_t idx = c0 + s_li;  // local pixel index
+    if (threadIdx.x == 0) o[0] = (double)(a.offset + idx);
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        const T x = reinterpret_cast<const T *>(pl.p[f])[idx];
+        o[1 + f] = (double)(scaled<T>(x, sp->scale[f], sp->minv[f]) - sp->mean[f]);
     }
 }
 
@@ -874,18 +962,18 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_sp = carve(sizeof(scaler_t<T>));
-    const size_t o_cen = carve(sizeof(T) * KMAX * RSSEG_MAX_FEATURES);
-    const size_t o_csq = carve(sizeof(T) * KMAX);
-    const size_t o_cand = carve(sizeof(double) * KPP_STRIDE * RSSEG_MAX_FEATURES);
-    const size_t o_cc = carve(sizeof(double) * KPP_STRIDE);
+    // centres + their squared norms, candidates + theirs: each pair contiguous, so that one copy uploads both
+    const size_t o_cen = carve(sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX));
+    const size_t o_cand = carve(sizeof(double) * ((size_t)KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE));
     const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
+    const size_t o_samp = carve(sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES));
+    const size_t o_qv = carve(sizeof(unsigned long long) * KPP_MAXL * (size_t)CHUNK);
     const size_t o_red = carve(sizeof(long long) * 2 * M);
     const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
     const size_t o_mom = carve(sizeof(long long) * (size_t)nblk * F);
     const size_t o_part = carve(sizeof(long long) * std::max<size_t>((size_t)M, KPP_MAXL) * (size_t)nchunks);
     const size_t dist_stride = (sizeof(T) * (size_t)std::max<int64_t>(n, 1) + 255) & ~(size_t)255;
     const size_t o_closest = carve(dist_stride);            // the ONE closest-distance plane of k-means++
-    const size_t o_chunk = carve(sizeof(T) * (size_t)CHUNK);  // current closest values of the chunk a sample falls into
     const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
@@ -895,16 +983,17 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     char *ws = ctx->d_ws;
     scaler_t<T> *d_sp = (scaler_t<T> *)(ws + o_sp);
     T *d_cen = (T *)(ws + o_cen);
-    T *d_csq = (T *)(ws + o_csq);
+    T *d_csq = d_cen + (size_t)KMAX * RSSEG_MAX_FEATURES;
     double *d_cand = (double *)(ws + o_cand);
-    double *d_cc = (double *)(ws + o_cc);
+    double *d_cc = d_cand + (size_t)KPP_STRIDE * RSSEG_MAX_FEATURES;
     T *d_row = (T *)(ws + o_row);
+    double *d_samp = (double *)(ws + o_samp);
+    unsigned long long *d_qv = (unsigned long long *)(ws + o_qv);
     long long *d_red = (long long *)(ws + o_red);
     T *d_mm = (T *)(ws + o_mm);
     long long *d_mom = (long long *)(ws + o_mom);
     long long *d_part = (long long *)(ws + o_part);
     T *d_closest = (T *)(ws + o_closest);
-    T *d_chunk = (T *)(ws + o_chunk);
     uint8_t *d_lab = (uint8_t *)(ws + o_lab);
     hipStream_t st = ctx->stream;
 
@@ -1020,10 +1109,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     };
     // candidate rows (columns 0..cnt-1) and the pending centre (column KPP_MAXL; may be null) as float64, transposed
     auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt, const T *pending) -> int {
-        double flat[KPP_STRIDE * RSSEG_MAX_FEATURES];
-        double cc[KPP_STRIDE];
+        double flat[KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE];  // [F][KPP_STRIDE] rows, then the KPP_STRIDE squared norms
+        double *cc = flat + KPP_STRIDE * RSSEG_MAX_FEATURES;
         memset(flat, 0, sizeof(flat));
-        memset(cc, 0, sizeof(cc));
         auto put = [&](const T *row, int col) {
             double a = 0.0;
             for (int f = 0; f < F; f++) {
@@ -1034,9 +1122,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         };
         for (int l = 0; l < cnt; l++) put(rows[l], l);
         if (pending) put(pending, KPP_MAXL);
-        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(double) * KPP_STRIDE * F, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(d_cc, cc, sizeof(double) * KPP_STRIDE, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));  // flat/cc live on this stack frame
+        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(flat), hipMemcpyHostToDevice, st));  // one copy: rows + norms
+        HIPCHK(ctx, hipStreamSynchronize(st));  // flat lives on this stack frame
         return RSSEG_OK;
     };
     // per-rank totals of the local chunk partials (row `row` of d_part), and the local prefix table
@@ -1123,6 +1210,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         int last_rank = 0;
         for (int rk = 0; rk < ctx->world; rk++)
             if (n_all[rk] > 0) last_rank = rk;
+        kpp_sample_args sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.with_old = c > 1 ? 1 : 0;
+        sa.offset = offset;
+        int mine = 0;
         for (int l = 0; l < L; l++) {
             const double r = rng.random_sample() * (double)current_pot;  // uniform(size=L) * current_pot
             const long double rl = ceill((long double)r * 1099511627776.0L);
@@ -1134,10 +1226,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 if (n_all[rk] > 0 && before + rank_tot[rk] >= target) { owner = rk; break; }
                 before += rank_tot[rk];
             }
-            int64_t li;  // local index of the sampled pixel on its owner
             if (owner < 0) {  // beyond the total: np.clip(candidate_ids, None, N-1) -> the last pixel of the last stripe
                 if (ctx->rank != last_rank) continue;
-                li = n - 1;
+                sa.mode[l] = 2;
+                sa.c0[l] = 0;
+                sa.direct[l] = n - 1;
             } else {
                 if (owner != ctx->rank) continue;
                 u128 run = before;
@@ -1147,27 +1240,24 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                     run += prefix_part[ch];
                 }
                 if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
-                const int64_t c0 = ch * CHUNK, cn = std::min<int64_t>(CHUNK, n - c0);
-                hipLaunchKernelGGL((km_kpp_chunk<T>), dim3((unsigned)ceil_div64(cn, KM_THREADS)), dim3(KM_THREADS), 0, st, pl, F, c0, cn, d_sp,
-                                   d_cand, d_cc, (const T *)d_closest, c > 1 ? 1 : 0, d_chunk);
-                HIPCHK(ctx, hipGetLastError());
-                HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_chunk, sizeof(T) * cn, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
-                const T *hv = (const T *)ctx->h_pin;
-                int64_t lc = cn - 1;
-                for (int64_t i = 0; i < cn; i++) {
-                    run += (u128)(unsigned long long)llrint((double)hv[i] * 1099511627776.0);
-                    if (run >= target) { lc = i; break; }
-                }
-                li = c0 + lc;
+                sa.mode[l] = 1;
+                sa.c0[l] = ch * CHUNK;
+                sa.cn[l] = std::min<int64_t>(CHUNK, n - sa.c0[l]);
+                sa.rem[l] = (unsigned long long)(target - run);  // <= the chunk's own sum: fits 64 bits
             }
-            double *xb = xbuf + (size_t)l * (1 + F);
-            xb[0] = (double)(offset + li);
-            hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li, d_sp, d_row);
+            mine++;
+        }
+        if (mine > 0) {  // one launch locates the pixels inside their chunks and gathers their rows; one copy back
+            hipLaunchKernelGGL((km_kpp_chunkq<T>), dim3((unsigned)(CHUNK / KM_THREADS), L), dim3(KM_THREADS), 0, st, pl, F, d_sp, d_cand, d_cc,
+                               (const T *)d_closest, sa, d_qv);
+            hipLaunchKernelGGL((km_kpp_sample<T>), dim3(L), dim3(KM_THREADS), 0, st, pl, F, d_sp, (const unsigned long long *)d_qv, sa, d_samp);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_samp, sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES), hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            for (int f = 0; f < F; f++) xb[1 + f] = (double)((const T *)ctx->h_pin)[f];
+            const double *hs = (const double *)ctx->h_pin;
+            for (int l = 0; l < L; l++)
+                if (sa.mode[l] != 0)
+                    for (int f = 0; f <= F; f++) xbuf[(size_t)l * (1 + F) + f] = hs[(size_t)l * (1 + RSSEG_MAX_FEATURES) + f];
         }
         RSCHK(comm_allreduce_host(ctx, xbuf, (int64_t)L * (1 + F), RSSEG_F64, RSSEG_SUM));
         T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
@@ -1229,9 +1319,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
     auto run_lloyd = [&](bool update) -> int {
         // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
-        T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS], csq[RSSEG_MAX_CLUSTERS];
+        T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS + RSSEG_MAX_CLUSTERS];  // [MAX_FEATURES][KMAX] centres, then KMAX norms
+        T *csq = cenT + (size_t)KMAX * RSSEG_MAX_FEATURES;
         memset(cenT, 0, sizeof(cenT));
-        memset(csq, 0, sizeof(csq));
         for (int j = 0; j < k; j++) {
             T a = (T)0;
             for (int f = 0; f < F; f++) {
@@ -1240,8 +1330,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             }
             csq[j] = a;
         }
-        HIPCHK(ctx, hipMemcpyAsync(d_cen, cenT, sizeof(T) * (size_t)F * KMAX, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(d_csq, csq, sizeof(T) * KMAX, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_cen, cenT, sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX), hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (n > 0) {
             {
