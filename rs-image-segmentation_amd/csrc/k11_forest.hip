@@ -46,17 +46,18 @@ struct rf_tree {
 };
 
 // One step of a walk: from node `nd` of a tree whose first `lim` nodes are in LDS (`buf`), the rest in `tn`.
-template <int RF_THREADS>
-__device__ __forceinline__ rf_node rf_step(const rf_node nd, const float *__restrict__ feat, const rf_node *__restrict__ buf, int lim,
-                                           const rf_node *__restrict__ tn)
+// The next node is fetched through ONE generic pointer (flat load: the aperture check per lane replaces a divergent
+// LDS / global branch pair).  NANS = false: the workgroup's pixels hold no NaN, so the missing-value rule is skipped.
+template <int RF_THREADS, bool NANS>
+__device__ __forceinline__ rf_node rf_step(const rf_node nd, const float *__restrict__ feat, const rf_node *buf, int lim, const rf_node *tn)
 {
     const float x = feat[((nd.bits >> 24) & 63u) * RF_THREADS + threadIdx.x];
     const unsigned left = nd.bits & 0xffffffu;
-    bool go_left;
-    if (x != x) go_left = (nd.bits & RF_MISS) != 0;
-    else go_left = x <= nd.thr;
-    const unsigned next = go_left ? left : left + 1u;
-    return (int)next < lim ? buf[next] : tn[next];
+    bool go_left = x <= nd.thr;
+    if (NANS) go_left = go_left || ((nd.bits & RF_MISS) != 0 && x != x);
+    const unsigned next = left + (go_left ? 0u : 1u);
+    const rf_node *p = (int)next < lim ? buf + next : tn + next;
+    return *p;
 }
 
 template <int NC>
@@ -87,7 +88,13 @@ __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, in
     float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_THREADS]
     rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_THREADS);       // [2 pairs][2 trees][ntop]
     const int64_t i = (int64_t)blockIdx.x * RF_THREADS + threadIdx.x;
-    for (int f = 0; f < F; f++) feat[f * RF_THREADS + threadIdx.x] = i < n ? pl.p[f][i] : 0.f;
+    int my_nan = 0;
+    for (int f = 0; f < F; f++) {
+        const float v = i < n ? pl.p[f][i] : 0.f;
+        my_nan |= v != v;
+        feat[f * RF_THREADS + threadIdx.x] = v;
+    }
+    const bool any_nan = __syncthreads_or(my_nan) != 0;  // workgroup-uniform
     constexpr int NPRE = 8192 / RF_THREADS;  // 2 * ntop <= 8192 nodes per pair
     // pair 0's top blocks
     for (int h = 0; h < 2 && h < n_trees; h++) {
@@ -129,9 +136,16 @@ __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, in
             const int limA = trA.n_nodes < ntop ? trA.n_nodes : ntop, limB = trB.n_nodes < ntop ? trB.n_nodes : ntop;
             rf_node a = bufA[0], b = two ? bufB[0] : a;
             if (!two) b.bits = RF_LEAF;
-            while (!((a.bits & b.bits) & RF_LEAF)) {
-                if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS>(a, feat, bufA, limA, tnA);
-                if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS>(b, feat, bufB, limB, tnB);
+            if (any_nan) {
+                while (!((a.bits & b.bits) & RF_LEAF)) {
+                    if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS, true>(a, feat, bufA, limA, tnA);
+                    if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS, true>(b, feat, bufB, limB, tnB);
+                }
+            } else {
+                while (!((a.bits & b.bits) & RF_LEAF)) {
+                    if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS, false>(a, feat, bufA, limA, tnA);
+                    if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS, false>(b, feat, bufB, limB, tnB);
+                }
             }
             rf_vote<NC>(a, trA, leafval, n_classes, acc);
             if (two) rf_vote<NC>(b, trB, leafval, n_classes, acc);
