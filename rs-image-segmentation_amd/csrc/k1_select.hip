@@ -156,7 +156,9 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
                             float *out_values, int64_t *n_nan_out)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const size_t hist_elems = (size_t)RSSEG_MAX_RANKS * SEL_BINS + 8;
+    // per plane: 8 words (NaN counter first) then up to RSSEG_MAX_RANKS tables of 2048 bins; only the tables a pass
+    // uses travel to the host and through the all-reduce
+    const size_t hist_elems = 8 + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
     const size_t hist_bytes = hist_elems * sizeof(unsigned long long);
     RSCHK(ws_reserve(ctx, (size_t)P * (hist_bytes + 256)));
     RSCHK(pin_reserve(ctx, (size_t)P * hist_bytes));
@@ -164,7 +166,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     uint32_t *d_pre_all = (uint32_t *)(ctx->d_ws + (size_t)P * hist_bytes);  // [P][64]
     long long *h_hist_all = (long long *)ctx->h_pin;
     if (ctx->world > 1 && (size_t)P * hist_bytes > ctx->comm_bytes)
-        return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
+        return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes may need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
 
     static bool attr_done = false;
     static int sel_threads = 1024;
@@ -235,8 +237,8 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         HIPCHK(ctx, hipMemsetAsync(d_hist_all, 0, (size_t)P * hist_bytes, ctx->stream));
         for (int p = 0; p < P; p++) {
             plane_state &S = st[p];
-            unsigned long long *d_hist = d_hist_all + (size_t)p * hist_elems;
-            unsigned long long *d_nan = d_hist + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
+            unsigned long long *d_nan = d_hist_all + (size_t)p * hist_elems;
+            unsigned long long *d_hist = d_nan + 8;
             const uint32_t *d_pre = d_pre_all + (size_t)p * 64;
             for (int b0 = 0; b0 < S.ndp; b0 += SEL_BATCH) {
                 prof_scope ps(ctx, "select");
@@ -248,15 +250,19 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
             }
         }
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(h_hist_all, d_hist_all, (size_t)P * hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        int max_tab = 1;
+        for (int p = 0; p < P; p++) max_tab = std::max(max_tab, st[p].ndp);
+        const size_t used_elems = 8 + (size_t)max_tab * SEL_BINS;  // per plane, compact on the host
+        HIPCHK(ctx, hipMemcpy2DAsync(h_hist_all, used_elems * 8, d_hist_all, hist_bytes, used_elems * 8, (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * hist_elems), RSSEG_I64, RSSEG_SUM));
+        RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * used_elems), RSSEG_I64, RSSEG_SUM));
         for (int p = 0; p < P; p++) {
             plane_state &S = st[p];
-            const long long *h_hist = h_hist_all + (size_t)p * hist_elems;
+            const long long *h_nanp = h_hist_all + (size_t)p * used_elems;
+            const long long *h_hist = h_nanp + 8;
             const int64_t *rk = ranks + (size_t)p * nranks;
             if (pass == 0) {
-                S.n_nan = h_hist[(size_t)RSSEG_MAX_RANKS * SEL_BINS];
+                S.n_nan = h_nanp[0];
                 S.n_global = S.n_nan;
                 for (int b = 0; b < SEL_BINS; b++) S.n_global += h_hist[b];
                 for (int r = 0; r < nranks; r++) {
