@@ -96,7 +96,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F &&f)
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// Batcher odd-even merge sort network for P elements (comparators touching padded slots pruned)
+// Sorting network for P elements: Batcher's merge exchange for an arbitrary count (Knuth, TAOCP 5.2.2, Algorithm M) —
+// 309 comparators at P = 42, 241 at P = 36 (the power-of-two odd-even merge sort with the padded slots pruned: 327, 268)
 template <int P> struct sort_net {
     int a[P * 12], b[P * 12];
     int n;
@@ -104,18 +105,23 @@ template <int P> struct sort_net {
 template <int P> constexpr sort_net<P> make_sort_net()
 {
     sort_net<P> s{};
-    int m = 1;
-    while (m < P) m *= 2;
+    int t = 0;
+    while ((1 << t) < P) t++;
     int n = 0;
-    for (int p = 1; p < m; p *= 2)
-        for (int k = p; k >= 1; k /= 2)
-            for (int j = k % p; j + k < m; j += 2 * k)
-                for (int i = 0; i < k && i + j + k < m; i++)
-                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p) && i + j + k < P) {
-                        s.a[n] = i + j;
-                        s.b[n] = i + j + k;
-                        n++;
-                    }
+    for (int p = t > 0 ? 1 << (t - 1) : 0; p > 0; p /= 2) {
+        int q = 1 << (t - 1), r = 0, d = p;
+        while (d > 0) {
+            for (int i = 0; i + d < P; i++)
+                if ((i & p) == r) {
+                    s.a[n] = i;
+                    s.b[n] = i + d;
+                    n++;
+                }
+            d = q - p;
+            q /= 2;
+            r = p;
+        }
+    }
     s.n = n;
     return s;
 }
