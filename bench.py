@@ -176,8 +176,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    meta = None
+    meta = labels = None
     for _ in range(args.warmup):
+        labels = None  # release the previous label plane first: the next step reuses its memory instead of growing the pool
         labels, meta = step()
     ctx.prof_enable(True)
     ctx.prof_reset()
@@ -186,8 +187,14 @@ def main():
         ctx._aux.prof_reset()
     barrier()
     t0 = time.perf_counter()
+    verbose = os.environ.get("RSSEG_BENCH_VERBOSE")
     for _ in range(args.steps):
+        ts = time.perf_counter()
+        labels = None
         labels, meta = step()
+        if verbose:  # per-step wall time (adds a device synchronisation per step: diagnostics only)
+            torch.cuda.synchronize()
+            print(f"[bench] step {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
