@@ -20,7 +20,7 @@ struct prof_entry {
 };
 
 struct forest_dev {
-    void *d_nodes = nullptr;    // packed 16-byte nodes
+    void *d_nodes = nullptr;    // packed 8-byte nodes (k11_forest.hip)
     void *d_leafval = nullptr;  // double[n_nodes_total][n_classes]
     void *d_treeoff = nullptr;  // int32[n_trees+1]
     int n_trees = 0, n_classes = 0, n_features = 0;

@@ -16,8 +16,8 @@
 //     or on how the raster is sharded over GPUs.
 //
 // Data movement per Lloyd iteration: F planes read once (4F B/px for float32) + 1 B/px label read
-// + 1 B/px label write; the tile is staged in LDS so the per-cluster accumulation re-reads it
-// on chip.  HBM-bound.
+// + 1 B/px label write; a lane keeps the F values of its pixels in registers from one batch of loads, so the
+// per-cluster accumulation (LDS atomics on bank-private copies) needs no second read.  HBM-bound.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -186,7 +186,7 @@ __global__ void km_gather_row(planes_t pl, int F, int64_t idx, const scaler_t<T>
 // One workgroup per chunk (km_chunk<T>() pixels), so partial[l][] is at once the potential of candidate l and,
 // for the candidate the host picks, the prefix table used to locate the next sampled pixel (np.searchsorted on
 // stable_cumsum, _kmeans.py:243-246): the chosen candidate's min-plane is never stored, the next round
-// re-derives it as its pending update (same arithmetic, same bits) and km_kpp_chunk does so for the one chunk a
+// re-derives it as its pending update (same arithmetic, same bits) and km_kpp_chunkq does so for the one chunk a
 // sample falls into.  Traffic per round: 4F + 8 B/px (read F planes + closest, write closest).
 // As in km_lloyd the F feature vectors of a lane's pixels are requested back to back into registers.
 // ------------------------------------------------------------------------------------------------
@@ -1200,7 +1200,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
 
     for (int c = 1; c < k; c++) {
         // centre c-1 is pending: its distances are folded into the closest plane by this round's pass, and by
-        // km_kpp_chunk for the chunks the samples fall into
+        // km_kpp_chunkq for the chunks the samples fall into
         RSCHK(upload_cands(nullptr, 0, C[c - 1]));
         int64_t cand_idx[KPP_MAXL];
         // xbuf[l] = {global pixel index, its F scaled+centred values}: filled by the rank that owns the pixel, zeros
