@@ -146,7 +146,19 @@ __global__ __launch_bounds__(KM_THREADS) void km_moment(planes_t pl, int64_t n, 
     const int f = blockIdx.y;
     const T sc = sp->scale[f], mnv = sp->minv[f];
     long long acc = 0;
-    for (int64_t base = ((int64_t)blockIdx.x * KM_THREADS + threadIdx.x) * PXL; base < n; base += (int64_t)gridDim.x * KM_THREADS * PXL) {
+    constexpr int UNR = 4;  // vector loads in flight per lane
+    const int64_t stride = (int64_t)gridDim.x * KM_THREADS * PXL;
+    int64_t base = ((int64_t)blockIdx.x * KM_THREADS + threadIdx.x) * PXL;
+    for (; base + (UNR - 1) * stride + PXL <= n; base += UNR * stride) {
+        T v[UNR][PXL];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) load_pxf<T, true>(pl.p[f], base + u * stride, n, v[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+            for (int i = 0; i < PXL; i++) acc += to_fixed40((double)scaled<T>(v[u][i], sc, mnv));
+    }
+    for (; base < n; base += stride) {
         T v[PXL];
         load_px<T>(pl.p[f], base, n, v);
 #pragma unroll
