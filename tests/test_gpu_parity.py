@@ -198,6 +198,22 @@ def test_glcm_bitexact_vs_oracle(ctx, oracle, win, step):
         assert np.array_equal(host(g, (oh, ow)), want[k]), (k, win, step)
 
 
+@pytest.mark.parametrize("levels,win,step", [(64, 7, 1), (64, 5, 3), (48, 3, 1), (16, 7, 2), (64, 11, 5)])
+def test_glcm_other_level_counts_bitexact_vs_oracle(ctx, oracle, levels, win, step):
+    """Level counts other than 32: up to 32 levels the window kernel pre-scales the pixels by 8, up to 64 by 4 (a second
+    instantiation with its own key layout and Hq table); larger windows take the workgroup-per-window kernel."""
+    rng = np.random.default_rng(levels * 1000 + win * 10 + step)
+    H, W = 61, 97
+    base = rng.integers(0, levels, (H, W))
+    smooth = (np.add.outer(3 * np.arange(H), np.arange(W)) // 7) % levels
+    q = np.where(rng.random((H, W)) < 0.5, base, smooth).astype(np.uint8)
+    q[30:45, 40:70] = levels - 1
+    want = oracle.glcm_small_maps(q, levels, win, step, mode=1)
+    got, (oh, ow) = ctx.glcm(dev(ctx, q), H, W, levels, win, step)
+    for g, k in zip(got, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
+        assert np.array_equal(host(g, (oh, ow)), want[k]), (k, levels, win, step)
+
+
 def test_glcm_dense_sliding_kernel_bitexact_vs_oracle(ctx, oracle):
     """Dense 7x7 / step 1 / 32 levels on a map wider than one strip (128 columns) and taller than one wave (64 rows,
     last wave partial): the sliding-window kernel against the oracle, all five properties bit for bit."""
@@ -472,6 +488,26 @@ def test_order_stats_multi_equals_single(ctx, scene, oracle):
         assert np.array_equal(vals[i], srt[ranks[i]], equal_nan=True), i
     with pytest.raises(ValueError):
         ctx.order_stats_multi(dv + dv[:1], ranks + ranks[:1])  # more than 8 planes
+
+
+def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
+    """More than four classes (the wider vote-accumulator instantiation), impure leaves, NaN features in some rows
+    (missing-value rule) and a pixel count that is not a multiple of the workgroup size."""
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(7)
+    Xtr = rng.random((6000, 19)).astype(np.float32)
+    ytr = (Xtr[:, 2] * 6).astype(np.int64) % 6
+    flip = rng.random(6000) < 0.2
+    ytr[flip] = rng.integers(0, 6, flip.sum())
+    model = RandomForestClassifier(n_estimators=25, max_depth=9, min_samples_leaf=3, random_state=1, n_jobs=4).fit(Xtr, ytr)
+    f = oracle.flatten_forest(model)
+    X = rng.random((5003, 19)).astype(np.float32)
+    X[::37, 2] = np.nan
+    X[5::53, 11] = np.nan
+    want = model.predict(X)
+    ctx.forest_load(f)
+    got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(19)]))
+    assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
 def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
