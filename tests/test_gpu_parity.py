@@ -162,6 +162,24 @@ def test_pca_vs_reference_goldens(ctx, crop):
     assert np.allclose(ratio3, crop["pca3_ratio"], atol=1e-6)
 
 
+@pytest.mark.parametrize("nb", [1, 2, 3, 5, 8])
+def test_pca_other_band_counts_vs_float64(ctx, crop, nb):
+    """The Gram / projection kernels are specialised on the band count: every instantiation other than 7 against the
+    float64 evaluation of the same estimator (components with a clear eigenvalue gap: 1e-5; all: variance ratios)."""
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(nb)
+    planes = [crop["norm"][i % 7] if i < 7 else (crop["norm"][0] * 0.5 + rng.random((96, 96), dtype=np.float32) * 0.5).astype(np.float32)
+              for i in range(nb)]
+    pcs, ratio, model = P.pca(ctx, [dev(ctx, b) for b in planes], None, True)
+    truth, evals = _pca_truth64(planes)
+    assert len(pcs) == nb and np.isclose(ratio.sum(), 1.0, atol=1e-5)
+    assert np.allclose(ratio, evals / evals.sum(), atol=1e-5)
+    gaps = np.minimum(np.abs(np.diff(evals, prepend=np.inf)), np.abs(np.diff(evals, append=-np.inf)))
+    for c in range(nb):
+        if nb == 1 or gaps[c] > 5e-2:
+            assert np.abs(host(pcs[c], (96, 96)).reshape(-1) - truth[c]).max() <= 1e-5, (nb, c)
+
+
 def test_pca_full_scene_vs_reference(ctx, scene, oracle, golden_dir):
     """600 x 600 scene.  At N = 360 000 the reference's float32 mean / sgemm accumulation is itself ~5e-5
     away from the float64 answer, so the 1e-5 bar is checked against float64 and the reference's own
