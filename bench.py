@@ -8,9 +8,13 @@ One "step" = one pass of the hot path over the raster already resident in HBM:
       GLCM (7x7 window, step 1, 32 levels, 4 angles, 5 properties, bilinear back to H x W) ->
       15 float32 features -> MinMax + KMeans(k=8, k-means++, random_state=42) -> int32 label plane
   config c2 (BASELINE configs[1]): 7 indices -> KMeans(k=6) on a 4096 x 4096 raster.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); ONE (N*H) x W scene is sharded by rows,
-every rank owns H rows (weak scaling) plus the few NIR halo rows its texture windows read; histograms, PCA
-sums and KMeans partials go through RCCL, and the label map equals the single-GPU result for that scene.
+  config c5 (BASELINE configs[4]): the 19-feature stack (indices, PCA, 7x7 context means, GLCM 21/21, 5x5 morphological
+      gradient, 5x5 local std, Sobel) -> RandomForest(100 trees, max_depth 16) inference -> int64 label plane.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  ONE H x W raster is sharded by rows over the N ranks
+("scaling": "strong" — BASELINE configs[3] / [4]: "16384x16384x7 ... tile-sharded across 8xMI355X"); every rank holds its
+stripe plus the halo rows its window operators read; histograms, PCA sums, KMeans partials and the Sobel maximum go through
+RCCL, and the label map equals the single-GPU result for that raster bit for bit (tests/test_gpu_dist.py).  --weak keeps H
+rows per rank instead (an (N*H) x W scene).
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,6 +33,8 @@ import numpy as np  # noqa: E402
 
 
 SYNTH_STRIPE = 2048
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
 def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
@@ -36,7 +42,7 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
     + N(0, 6) noise, clipped, truncated to uint8, stored as float32 (integer-valued DN like the real
     preprocessed tile).  Returns the planes `want` for GLOBAL rows [g0, g1); every 2048-row stripe of the scene
     has its own seed and is always generated whole, so any rank reproduces any row of the scene exactly
-    (needed for the texture halos of a row-sharded raster)."""
+    (needed for the halos of a row-sharded raster)."""
     proto = torch.tensor(np.random.default_rng(355).integers(20, 230, (8, bands)), dtype=torch.float32, device=device)
     want = list(want)
     out = {b: torch.empty((g1 - g0) * W, dtype=torch.float32, device=device) for b in want}
@@ -56,56 +62,91 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
     return [out[b] for b in want]
 
 
-# algorithmic HBM bytes per pixel and launch of each kernel family
-def algorithmic_bytes_per_px(family, F, glcm_step, k=8):
+# ---- roofline bookkeeping --------------------------------------------------------------------------------------------
+def family_table(cfg, F, glcm_step, k, n_pca):
+    """kernel family -> (bound, algorithmic HBM bytes per pixel and launch) — SURVEY.md §8(d), DESIGN.md §5.
+    'lloyd' is charged the bytes it moves (F float32 planes + uint8 label read + write), not int32 labels."""
+    idx_out = 7 * 4 + (4 if cfg == "c3" else (20 if cfg == "c5" else 0))   # + the normalised bands the config keeps
     return {
-        "glcm": 4 + 20.0 / (glcm_step * glcm_step),   # read plane once, write 5 property maps
-        "lloyd": 4 * F + 8,                            # F float32 features + label read/write
-        # k passes: first centre reads F planes; round 1 also writes the closest plane; later rounds read + write it
-        "kpp": (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1),
-        "select": 4,                                   # one radix pass over one float32 plane
-        "indices": 20 + 28 + 4,                        # 5 bands in, 7 indices + the normalised NIR band out
-        "gram": 28, "project": 28 + 12, "resize": 8, "box": 8, "stencil": 8, "forest": 4 * F + 8,
-    }[family]
+        "kpp": ("hbm", (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1)),   # k passes: F planes in, closest plane r/w from round 2 on
+        "lloyd": ("hbm", 4 * F + 2),
+        "select": ("hbm", 4),                                              # one radix pass over one float32 plane
+        "indices": ("hbm", 20 + idx_out),
+        "gram": ("hbm", 28), "project": ("hbm", 28 + 4 * n_pca),
+        "resize": ("hbm", 8),                                              # 4 taps from cache, one plane out
+        "box": ("hbm", 8), "ctxmean": ("hbm", 8 * 7), "morph": ("hbm", 2), "filt_max": ("hbm", 1), "filt_write": ("hbm", 5),
+        "glcm": ("valu", 4 + 20.0 / (glcm_step * glcm_step)),
+        "forest": ("latency", 4 * F + 8),
+    }
 
 
-# kernel family -> name of its dominant kernel in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
+# dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
 PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7, 3>",
-              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>", "resize": "k5_resize<true>"}
+              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>",
+              "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
+# static VALU instructions one wave executes per 64 windows in k4_glcm_thread<7,3> and their measured issue cost
+# (profiles/r02_valu_issue_microbench.md): the bound of the texture kernel is VALU issue, not HBM
+GLCM_VALU = {"insts_per_wave": 2996, "issue_cycles_per_wave": None}
 
 
 def pmc_traffic_bytes(family, px):
-    """HBM bytes per launch of the family's dominant kernel from the committed PMC summary (FETCH_SIZE
-    doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None when no summary is available."""
+    """HBM bytes per launch of the family's dominant kernel from the newest committed PMC summary (FETCH_SIZE
+    doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None when that kernel is not in a summary."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files or family not in PMC_KERNEL:
+    if family not in PMC_KERNEL:
         return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:  # noqa: BLE001
+            continue
+        for name, kk in ks.items():
+            if name.startswith(PMC_KERNEL[family]):
+                return round((kk["read_B_per_px"] + kk["write_B_per_px"]) * px)
+    return None
+
+
+def glcm_issue_cycles():
+    """Weighted VALU issue cycles per window-wave from the committed microbenchmark summary, if present."""
+    f = os.path.join(ROOT, "profiles", "r02_valu_issue.json")
     try:
-        k = json.load(open(files[-1]))["kernels"].get(PMC_KERNEL[family])
-        return None if k is None else round((k["read_B_per_px"] + k["write_B_per_px"]) * px)
+        return json.load(open(f))["glcm_thread_7_3"]["issue_cycles_per_wave"]
     except Exception:  # noqa: BLE001
         return None
 
 
-def cpu_baseline(O, tile_bands, H, W, crop, cfg, k):
-    """Oracle ("port", single thread) on a crop of the same raster; returns (Mpx/s, description)."""
-    from threadpoolctl import threadpool_limits
+# ---- CPU baseline (rank 0, N = 1) -------------------------------------------------------------------------------------
+def cpu_baseline(tile_bands, H, W, crop, cfg, k, glcm_step, model=None):
+    """the CPU counterpart harness (oracle/cpu_harness.py: NumPy glue restated + the scikit-learn
+    estimators the reference calls + C restatements of the cv2 / skimage stages) on a crop of the same raster, once with
+    every host core and once with one thread.  The single-threaded C GLCM is timed once and used in both figures."""
+    from oracle import cpu_harness as CH
     c = min(crop, H, W)
     b = [t.reshape(H, W)[:c, :c].cpu().numpy().copy() for t in tile_bands]
-    t0 = time.perf_counter()
-    with threadpool_limits(limits=1):
-        norm = [O.robust_normalize(x) for x in b]
-        bl, g, r, n, s = norm[:5]
-        feats = [O.calculate_ndvi(n, r), O.calculate_evi(n, r, bl), O.calculate_msavi(n, r), O.calculate_ndwi(g, n),
-                 O.calculate_mndwi(g, s), O.calculate_ndbi(s, n), O.calculate_bsi(bl, r, n, s)]
-        if cfg == "c3":
-            pcs, _, _ = O.perform_pca(norm, n_components=3)
-            gl, _ = O.calculate_glcm_features(norm[3], 32, 7, 1)
-            feats = feats + [gl[x] for x in ("contrast", "dissimilarity", "homogeneity", "energy", "correlation")] + list(pcs)
-        O.kmeans_fit_planes(feats, k)
-    dt = time.perf_counter() - t0
-    return (c * c / 1e6) / dt, f"{c}x{c}x7 crop of the same synthetic raster, full {cfg} path, oracle C/NumPy port, 1 thread, {dt:.1f} s"
+    px = c * c / 1e6
+    if cfg == "c5":
+        allc = CH.config5(b, model, None)
+        one = CH.config5(b, model, 1)
+        tot_all, tot_one = allc["features"] + allc["forest"], one["features"] + one["forest"]
+        stages = {"all_cores": {s: round(v, 3) for s, v in allc.items()}, "one_thread": {s: round(v, 3) for s, v in one.items()}}
+    else:
+        allc = CH.config23(b, cfg, k, glcm_step, None)
+        gl = (allc["glcm"], allc.pop("_glcm_planes")) if cfg == "c3" else None
+        one = CH.config23(b, cfg, k, glcm_step, 1, gl)
+        keys = [s for s in allc if s != "n_iter"]
+        tot_all, tot_one = sum(allc[s] for s in keys), sum(one[s] for s in keys)
+        stages = {"all_cores": {s: round(allc[s], 3) for s in keys}, "one_thread": {s: round(one[s], 3) for s in keys},
+                  "kmeans_n_iter": allc["n_iter"]}
+    ti = CH.thread_info()
+    threads = max([p["threads"] or 1 for p in ti["pools"]] + [1])
+    return {"value": round(px / tot_all, 4), "unit": "Mpixel/s", "cores": threads, "kind": "port",
+            "host_cores": ti["host_cores"], "threads": threads, "threadpools": ti["pools"],
+            "value_all_cores": round(px / tot_all, 4), "value_1_thread": round(px / tot_one, 4), "stage_seconds": stages,
+            "sample": (f"{c}x{c}x7 crop of the same synthetic raster, full {cfg} path: NumPy glue restated + scikit-learn "
+                       "RobustScaler/PCA/MinMaxScaler/KMeans" + ("/RandomForest.predict" if cfg == "c5" else "")
+                       + " + C/NumPy restatements of the cv2/skimage stages"
+                       + ("; GLCM (single-threaded C, " f"{allc['glcm']:.1f} s) timed once and counted in both figures" if cfg == "c3" else "")
+                       + f"; extrapolated linearly in pixels to the full raster; {tot_all:.1f} s all cores, {tot_one:.1f} s one thread")}
 
 
 def main():
@@ -114,10 +155,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
-    ap.add_argument("--size", type=int, default=0, help="tile edge (default 16384 for c3, 4096 for c2)")
+    ap.add_argument("--size", type=int, default=0, help="raster edge (default 16384 for c3 / c5, 4096 for c2)")
     ap.add_argument("--glcm-step", type=int, default=1)
-    ap.add_argument("--cpu-crop", type=int, default=2048)
+    ap.add_argument("--cpu-crop", type=int, default=1536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and GLCM-step-7 side measurements")
+    ap.add_argument("--weak", action="store_true", help="N > 1: H rows per rank ((N*H) x W scene) instead of one H x W raster split N ways")
+    ap.add_argument("--overlap", action="store_true", help="c3, N = 1: GLCM chain on a second HIP stream (profiles/r01_overlap_note.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -143,32 +187,49 @@ def main():
     from rsseg.runtime import Context
     ctx = Context(local)
 
-    H = W = args.size or (4096 if args.config == "c2" else 16384)
-    k = 8 if args.config == "c3" else 6
-    F = {"c2": 7, "c3": 15, "c5": 19}[args.config]
-    n_global = H * W * world
-    Hg, r0, r1 = H * world, rank * H, (rank + 1) * H       # one (world*H) x W scene, this rank owns rows [r0, r1)
-    bands = synth_rows(torch, device, W, r0, r1)
-    nir_ext, i0 = None, r0
-    if world > 1 and args.config == "c3":
-        _, _, i0, i1 = P.glcm_halo_rows(Hg, r0, r1, 7, args.glcm_step)
-        top = synth_rows(torch, device, W, i0, r0, want=[3])[0] if i0 < r0 else bands[3][:0]
-        bot = synth_rows(torch, device, W, r1, i1, want=[3])[0] if i1 > r1 else bands[3][:0]
-        nir_ext = torch.cat([top, bands[3], bot])
+    cfg = args.config
+    H = W = args.size or (4096 if cfg == "c2" else 16384)
+    k = 8 if cfg == "c3" else 6
+    F = {"c2": 7, "c3": 15, "c5": 19}[cfg]
+    n_pca = {"c2": 0, "c3": 3, "c5": 7}[cfg]
+    weak = args.weak and world > 1
+    Hg = H * world if weak else H                      # rows of the ONE raster all ranks work on
+    r0, r1 = (rank * H, (rank + 1) * H) if weak else P.stripe_rows(Hg, world, rank)
+    n_global = Hg * W
+    n_own = (r1 - r0) * W
+
+    # ---- this rank's resident input: its stripe, plus halo rows when the raster is sharded ----
+    nir_ext, i0, e0 = None, r0, r0
+    if cfg == "c5" and world > 1:
+        e0, e1 = P.stack19_halo_rows(Hg, r0, r1)
+        bands = synth_rows(torch, device, W, e0, e1)                      # rows [e0, e1) of every band
+    else:
+        bands = synth_rows(torch, device, W, r0, r1)
+        if cfg == "c3" and world > 1:
+            _, _, i0, i1 = P.glcm_halo_rows(Hg, r0, r1, 7, args.glcm_step)
+            top = synth_rows(torch, device, W, i0, r0, want=[3])[0] if i0 < r0 else bands[3][:0]
+            bot = synth_rows(torch, device, W, r1, i1, want=[3])[0] if i1 > r1 else bands[3][:0]
+            nir_ext = torch.cat([top, bands[3], bot])
     torch.cuda.synchronize()
 
     forest_model = None
-    if args.config == "c5":
-        forest_model = fit_c5_forest(ctx, P, bands, H, W, n_global)
+    if cfg == "c5":
+        forest_model = fit_c5_forest(torch, dist, device, P, rank, world, W)
+        ctx.forest_load(forest_model["flat"])
 
-    def step():
-        if args.config == "c3" and world > 1:
-            labels, meta, _ = P.config3_striped(ctx, bands, nir_ext, Hg, W, r0, r1, i0, k, 7, args.glcm_step, 3)
+    def step(glcm_step=args.glcm_step):
+        if cfg == "c3" and world > 1:
+            labels, meta, _ = P.config3_striped(ctx, bands, nir_ext, Hg, W, r0, r1, i0, k, 7, glcm_step, 3)
             return labels, meta
-        if args.config == "c3":
-            return run_c3(ctx, P, bands, H, W, k, args.glcm_step, n_global)
-        if args.config == "c5":
-            return run_c5(ctx, P, bands, H, W, n_global)
+        if cfg == "c3":
+            labels, meta, _ = P.config3(ctx, bands, H, W, k, 7, glcm_step, 3, n_global, overlap=args.overlap)
+            return labels, meta
+        if cfg == "c5" and world > 1:
+            planes, _ = P.stack19_striped(ctx, bands, Hg, W, r0, r1, e0)
+            return ctx.forest_predict(P.stack19_forest_planes(ctx, planes)), None
+        if cfg == "c5":
+            planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
+            return ctx.forest_predict(P.stack19_forest_planes(ctx, planes)), None
         return run_c2(ctx, P, bands, k, n_global)
 
     def barrier():
@@ -202,7 +263,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fams = {}
-    for fam in ("glcm", "lloyd", "kpp", "select", "indices", "gram", "project", "resize", "forest", "box", "stencil"):
+    for fam in family_table(cfg, F, args.glcm_step, k, n_pca):
         ms, cnt = ctx.prof_get(fam)
         if getattr(ctx, "_aux", None) is not None:  # kernels issued on the second stream
             ms2, cnt2 = ctx._aux.prof_get(fam)
@@ -212,42 +273,83 @@ def main():
     comm_ms, comm_cnt = ctx.prof_get("allreduce")
     ctx.prof_enable(False)
 
+    # ---- side measurements (rank 0, N = 1): the GLCM step-7 variant and the PCIe-inclusive rate ----
+    extras = {}
+    if world == 1 and not args.no_extras:
+        if cfg == "c3" and args.glcm_step == 1:
+            labels = None
+            step(7)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(2):
+                labels = None
+                labels, _m = step(7)
+            torch.cuda.synchronize()
+            t7 = (time.perf_counter() - ts) / 2
+            extras["glcm_step7"] = {"ms_per_step": round(t7 * 1e3, 2), "value": round(n_global / 1e6 / t7, 2),
+                                    "note": "same path with step_size=7 (the reference's non-overlapping windows, SURVEY.md 8d)"}
+        extras["pcie_inclusive"] = pcie_inclusive(torch, device, bands, step, n_global)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_global / 1e6 / (dt / args.steps)
-        dom = max(fams, key=lambda f: fams[f][0]) if fams else None
-        roof = None
-        if dom:
-            ms, cnt = fams[dom]
+        table = family_table(cfg, F, args.glcm_step, k, n_pca)
+        kernels = []
+        visits = (forest_visits_per_px(torch, P, ctx, bands, H, W, n_global, forest_model["model"])
+                  if (cfg == "c5" and world == 1 and "forest" in fams) else None)
+        for fam, (ms, cnt) in sorted(fams.items(), key=lambda kv: -kv[1][0]):
+            bound, bpp = table[fam]
             per_launch_s = ms / cnt / 1e3
-            px = H * W if dom != "glcm" else ((H - 7) // args.glcm_step + 1) * ((W - 7) // args.glcm_step + 1)
-            bpp = algorithmic_bytes_per_px(dom, F, args.glcm_step, k)
-            achieved = px * bpp / per_launch_s / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_bytes(dom, px) if H == 16384 else None,
-                    "algorithmic_bytes": round(px * bpp),
-                    "avg_launch_ms": round(ms / cnt, 4), "launches_per_step": cnt / args.steps,
-                    "family_ms_per_step": {f: round(v[0] / args.steps, 3) for f, v in fams.items()}}
+            px = n_own if fam != "glcm" else max((r1 - r0 - 7) // args.glcm_step + 1, 1) * ((W - 7) // args.glcm_step + 1)
+            ent = {"name": fam, "bound": bound, "avg_ms": round(ms / cnt, 4), "launches_per_step": cnt / args.steps,
+                   "ms_per_step": round(ms / args.steps, 3), "algorithmic_B_per_px": round(bpp, 2),
+                   "hbm_GBs": round(px * bpp / per_launch_s / 1e9, 1), "hbm_frac": round(px * bpp / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)}
+            if bound == "hbm":
+                ent["frac"] = ent["hbm_frac"]
+            elif bound == "valu":
+                cyc = glcm_issue_cycles()
+                waves = px / 64.0
+                if cyc is not None:
+                    ent["frac"] = round(waves * cyc / (N_SIMD * CLOCK_HZ * per_launch_s), 4)
+                    ent["valu_issue_cycles_per_wave"] = cyc
+                else:  # nominal 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md) until the microbenchmark is committed
+                    ent["frac"] = round(waves * GLCM_VALU["insts_per_wave"] * 2 / (N_SIMD * CLOCK_HZ * per_launch_s), 4)
+                ent["valu_insts_per_wave"] = GLCM_VALU["insts_per_wave"]
+            elif bound == "latency" and visits:
+                ent["node_visits_per_px"] = round(visits, 1)
+                ent["node_visits_per_s"] = round(px * visits / per_launch_s, 0)
+                ent["frac"] = None
+            kernels.append(ent)
+        roof = None
+        if kernels:
+            dom = kernels[0]                      # the family with the most time per step
+            hbm = [e for e in kernels if e["bound"] == "hbm"]
+            lead = dom if dom["bound"] == "hbm" or not hbm else hbm[0]
+            px = n_own
+            roof = {"bound": lead["bound"], "kernel": lead["name"], "achieved": lead["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": lead["hbm_frac"], "traffic": pmc_traffic_bytes(lead["name"], px) if (H == 16384 and world == 1) else None,
+                    "algorithmic_bytes": round(px * lead["algorithmic_B_per_px"]), "avg_launch_ms": lead["avg_ms"],
+                    "dominant_by_time": dom["name"], "kernels": kernels}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import ref_np as O
-            if args.config == "c5":
-                v, desc = cpu_baseline_c5(O, forest_model, bands, H, W, min(args.cpu_crop, 1024))
-            else:
-                v, desc = cpu_baseline(O, bands, H, W, args.cpu_crop, args.config, k)
-            cpu = {"value": round(v, 4), "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": desc}
+            cpu = cpu_baseline(bands, H, W, min(args.cpu_crop, 1024) if cfg == "c5" else args.cpu_crop, cfg, k, args.glcm_step,
+                               forest_model["model"] if forest_model else None)
+        scene = f"{Hg}x{W}x7 synthetic TM raster" + (f", row-striped over {world} GPUs ({r1 - r0} rows per rank + halo rows)" if world > 1 else "")
         out = {
             "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{H}x{W}x7 synthetic TM raster per GPU ({H * world}x{W} scene row-striped over {world} GPU(s)), robust-normalise + 7 spectral indices"
-                                    + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if args.config == "c3" else "")
-                                    + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if args.config != "c5" else
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (scene + ", robust-normalise + 7 spectral indices"
+                                    + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if cfg == "c3" else "")
+                                    + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if cfg != "c5" else
                                        " + PCA + GLCM(21/21) + 7x7 context + morphology/std/Sobel -> 19-feature stack -> RandomForest(100 trees, max_depth 16) inference")),
-                       "tile": [H, W, 7], "n_features": F, "n_clusters": k if args.config != "c5" else None,
+                       "baseline_config": {"c2": "configs[1]", "c3": "configs[2]" if world == 1 else "configs[3]", "c5": "configs[4]"}[cfg],
+                       "raster": [Hg, W, 7], "rows_per_rank": r1 - r0, "n_features": F, "n_clusters": k if cfg != "c5" else None,
                        "kmeans_n_iter": int(meta["n_iter"]) if meta else None,
-                       "parallelism": f"row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials",
-                       "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3)},
+                       "parallelism": (f"one raster row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials / Sobel max"
+                                       if world > 1 else "single GPU"),
+                       "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3),
+                       **extras},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
@@ -261,46 +363,95 @@ def _label_field(H, W, row0=0):
     return ((y // 64) * 7 + (x // 64) * 3) % 8
 
 
-def fit_c5_forest(ctx, P, bands, H, W, n_global):
-    """BASELINE config 5: RandomForestClassifier(100, max_depth=16, random_state=42) fitted on the host on
-    200 000 pixels of the 19-feature stack with the prototype index as label and 10 % label noise, so that
-    depth 16 is reached; same object schema as the reference's rf_samples_model.pkl.  Training is outside
-    the timed region (out of scope)."""
-    import torch
-    from sklearn.ensemble import RandomForestClassifier
+def fit_c5_forest(torch, dist, device, P, rank, world, W):
+    """BASELINE config 5: RandomForestClassifier(100, max_depth=16, random_state=42) fitted on the host on 200 000 pixels
+    of the 19-feature stack of the first 2048 rows of the scene (prototype index as label, 10 % label noise, so that
+    depth 16 is reached); same object schema as the reference's rf_samples_model.pkl.  Rank 0 fits and broadcasts the
+    flattened forest, so every rank walks the same trees whatever the sharding.  Training is outside the timed region
+    (out of scope)."""
     from rsseg.forest import flatten_forest
-    planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
-    fp = P.stack19_forest_planes(ctx, planes)
-    rng = np.random.default_rng(355)
-    idx = rng.choice(H * W, 200000, replace=False)
-    ti = torch.from_numpy(idx).to(fp[0].device)
-    X = np.stack([p[ti].cpu().numpy() for p in fp], 1)
-    y = _label_field(H, W).reshape(-1)[idx].astype(np.int64)
-    flip = rng.random(idx.size) < 0.1
-    y[flip] = rng.integers(0, 8, int(flip.sum()))
-    model = RandomForestClassifier(n_estimators=100, max_depth=16, random_state=42, n_jobs=-1).fit(X, y)
-    ctx.forest_load(flatten_forest(model))
-    return model
+    from rsseg.runtime import Context
+    model = flat = None
+    if rank == 0:
+        from sklearn.ensemble import RandomForestClassifier
+        Ht = min(2048, W)
+        c0 = Context(device.index, use_dist=False)
+        tb = synth_rows(torch, device, W, 0, Ht)
+        planes, _ = P.feature_stack19(c0, tb, Ht, W)
+        fp = P.stack19_forest_planes(c0, planes)
+        rng = np.random.default_rng(355)
+        idx = rng.choice(Ht * W, 200000, replace=False)
+        ti = torch.from_numpy(idx).to(device)
+        X = np.stack([p[ti].cpu().numpy() for p in fp], 1)
+        y = _label_field(Ht, W).reshape(-1)[idx].astype(np.int64)
+        flip = rng.random(idx.size) < 0.1
+        y[flip] = rng.integers(0, 8, int(flip.sum()))
+        model = RandomForestClassifier(n_estimators=100, max_depth=16, random_state=42, n_jobs=-1).fit(X, y)
+        flat = flatten_forest(model)
+        c0.close()
+        del tb, planes, fp
+        torch.cuda.empty_cache()
+    if world > 1:
+        box = [flat]
+        dist.broadcast_object_list(box, src=0)
+        flat = box[0]
+    return {"model": model, "flat": flat}
 
 
-def run_c5(ctx, P, bands, H, W, n_global):
-    planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
-    labels = ctx.forest_predict(P.stack19_forest_planes(ctx, planes))
-    return labels, None
+def forest_visits_per_px(torch, P, ctx, bands, H, W, n_global, model, sample=65536):
+    """Average number of tree nodes a pixel visits over the whole forest (leaf included), from sklearn's own apply() on
+    a sample of the feature rows the GPU walks: turns the forest kernel's time into node visits per second."""
+    try:
+        planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
+        fp = P.stack19_forest_planes(ctx, planes)
+        idx = torch.from_numpy(np.random.default_rng(1).choice(H * W, sample, replace=False)).to(fp[0].device)
+        X = np.stack([p[idx].cpu().numpy() for p in fp], 1)
+        tot = 0.0
+        for est in model.estimators_:
+            t = est.tree_
+            left, right = t.children_left, t.children_right
+            depth = np.zeros(t.node_count, np.int32)
+            for nd in range(t.node_count):                  # parents precede children in sklearn's node order
+                if left[nd] != -1:
+                    depth[left[nd]] = depth[nd] + 1
+                    depth[right[nd]] = depth[nd] + 1
+            tot += float((depth[t.apply(X)] + 1).mean())
+        return tot
+    except Exception:  # noqa: BLE001
+        return None
 
 
-def cpu_baseline_c5(O, model, tile_bands, H, W, crop):
-    """Oracle feature stack + the same sklearn forest (n_jobs=None, as the reference calls it) on a crop."""
-    from threadpoolctl import threadpool_limits
-    c = min(crop, H, W)
-    b = [t.reshape(H, W)[:c, :c].cpu().numpy().copy() for t in tile_bands]
-    t0 = time.perf_counter()
-    with threadpool_limits(limits=1):
-        _, hier = O.run_feature_extraction_stage(b)
-        model.n_jobs = None
-        model.predict(hier["all"].reshape(-1, 19))
-    dt = time.perf_counter() - t0
-    return (c * c / 1e6) / dt, f"{c}x{c}x7 crop, oracle 19-feature stack + sklearn forest.predict (n_jobs=None), 1 thread, {dt:.1f} s"
+def pcie_inclusive(torch, device, bands, step, n_global):
+    """One step with the 7 bands coming from pinned host memory and the labels going back to it (transfers not overlapped
+    with compute): the second figure SURVEY.md §8d asks for.  Never the bench `value`."""
+    try:
+        host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in bands]
+        for h, b in zip(host, bands):
+            h.copy_(b)
+        torch.cuda.synchronize()
+        step()                                  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for h, b in zip(host, bands):
+            b.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        labels, _ = step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        lab_host = torch.empty(labels.numel(), dtype=labels.dtype, pin_memory=True)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        lab_host.copy_(labels, non_blocking=True)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        tot = (t1 - t0) + (t2 - t1) + (t4 - t3)
+        gb = sum(b.numel() * 4 for b in bands) / 1e9
+        return {"value": round(n_global / 1e6 / tot, 2), "unit": "Mpixel/s", "h2d_ms": round((t1 - t0) * 1e3, 1), "h2d_GBs": round(gb / (t1 - t0), 1),
+                "compute_ms": round((t2 - t1) * 1e3, 1), "d2h_labels_ms": round((t4 - t3) * 1e3, 1),
+                "note": "7 bands pinned host -> HBM, one step, labels -> pinned host; transfers not overlapped with compute"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def run_c2(ctx, P, bands, k, n_global):
@@ -308,11 +459,6 @@ def run_c2(ctx, P, bands, k, n_global):
     idx, _ = P.spectral_indices(ctx, bands, lohi)
     planes = [idx[n] for n in P.INDEX_NAMES]
     return ctx.kmeans_fit_predict(planes, k)
-
-
-def run_c3(ctx, P, bands, H, W, k, glcm_step, n_global):
-    labels, meta, _ = P.config3(ctx, bands, H, W, k, 7, glcm_step, 3, n_global, overlap=os.environ.get("RSSEG_OVERLAP", "0") == "1")
-    return labels, meta
 
 
 if __name__ == "__main__":

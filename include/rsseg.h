@@ -83,7 +83,8 @@ int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn f
 
 /* Per-kernel timing (HIP events on the context's stream, around each launch of the named
  * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices",
- * "select", "kpp", "box", "project", "gram", "forest", "resize", "stencil". */
+ * "select", "kpp", "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
+ * of Sobel / Laplacian), "project", "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
 int rsseg_prof_enable(rsseg_ctx *ctx, int on);
 int rsseg_prof_reset(rsseg_ctx *ctx);
 int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
@@ -137,6 +138,18 @@ int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *const *d_bands,
                                     float *components, float *explained_variance_ratio, float *mean,
                                     float *explained_variance);
 
+/* The same with the FIT restricted to the pixels [fit_off, fit_off + fit_n) of the planes while all n_local pixels are
+ * projected: a rank of a row-sharded raster passes its stripe plus halo rows (the 7x7 context mean of the first
+ * component needs 3 rows either side, indices.py:770) and fits on the rows it owns.  lohi may be NULL (bands already
+ * normalised), center / scale may be NULL (no RobustScaler). */
+int rsseg_pca_fit_transform_ext_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off,
+                                    int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
+                                    float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
+                                    float *explained_variance);
+/* Errors of the three PCA entry points: RSSEG_ERR_INVALID "Input X contains NaN." / "... infinity" (sklearn's PCA raises
+ * ValueError on such input, sklearn/utils/validation.py); bands that are not robust-normalised are range-checked
+ * with one extra pass so that the exact fixed-point accumulation fits any finite input (raw DN, reflectances). */
+
 /* ---- K4/K5: GLCM texture + bilinear upsample ------------------------------------------- */
 /* calculate_glcm_features (indices.py:248-318), window loop: d_q is the quantised uint8 plane
  * ((band*(levels-1)).astype(uint8), :268), H x W.  Writes the five property maps
@@ -161,14 +174,26 @@ int rsseg_resize_bilinear_rows_f32(rsseg_ctx *ctx, const float *d_src, int sh_lo
                                    float *d_dst, int dh_local, int dw, int dst_row0, int dh);
 
 /* ---- K6/K7/K8: window operators ---------------------------------------------------------- */
-/* cv2.boxFilter(normalize=True) / cv2.blur for float32 (indices.py:770-771, 537, 541): k x k mean,
- * float64 sums, border RSSEG_BORDER_*.  If square != 0 the input is squared (float32) first
- * (blur(band*band), indices.py:541).  d_out64 (optional) receives the same values as float64
- * (add_spatial_context writes into a float64 buffer, indices.py:765). */
+/* Every operator exists in a ROWS form for row-sharded rasters: the plane holds Hin rows, rows
+ * [y0, y1) are produced into a compact (y1 - y0) x W output.  edges bit 0 / bit 1 say that row 0 / row Hin - 1 is the
+ * image's first / last row, where the operator's border rule applies; a side that is not an image edge must carry
+ * R = k/2 halo rows (2R for opening / closing), otherwise RSSEG_ERR_INVALID.  The plain forms are rows (0, H), edges 3.
+ * The stripes of a sharded raster get exactly the rows of the un-sharded result. */
+/* cv2.boxFilter(normalize=True) / cv2.blur for float32 (indices.py:770-771, 537, 541): k x k mean, k in {3,5,7,9},
+ * float64 sums in a fixed order (row sums left to right, then top to bottom), border RSSEG_BORDER_*.  If square != 0
+ * the input is squared (float32) first (blur(band*band), indices.py:541). */
 int rsseg_box_mean_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, int border, int square,
                        float *d_out);
+/* The same for nplanes (<= 8) planes of equal shape in ONE launch (add_spatial_context loops over 7 channels). */
+int rsseg_box_mean_rows_f32(rsseg_ctx *ctx, const float *const *d_x, int nplanes, int Hin, int W, int y0, int y1, int edges,
+                            int k, int border, int square, float *const *d_out);
 /* std_dev_scale_k (indices.py:537-548): sqrt(max(blur(x*x) - blur(x)^2, 0)), REFLECT_101. */
 int rsseg_local_std_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
+/* variance_scale_k (indices.py:541-544): max(blur(x*x) - blur(x)^2, 0), REFLECT_101 (rsseg_local_std_f32 without the sqrt). */
+int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
+/* rows form of both: variance != 0 selects variance_scale_k */
+int rsseg_local_std_rows_f32(rsseg_ctx *ctx, const float *d_x, int Hin, int W, int y0, int y1, int edges, int k, int variance,
+                             float *d_out);
 /* cv2.morphologyEx(MORPH_GRADIENT, ones(k,k)) on uint8 (indices.py:422, 433); output uint8. */
 int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, uint8_t *d_out);
 /* cv2.erode / cv2.dilate / cv2.morphologyEx(MORPH_OPEN | MORPH_CLOSE | MORPH_GRADIENT) with ones(k,k) on uint8
@@ -180,14 +205,17 @@ int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, in
 #define RSSEG_MORPH_CLOSE 3
 #define RSSEG_MORPH_GRADIENT 4
 int rsseg_morph_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out);
-/* variance_scale_k (indices.py:541-544): max(blur(x*x) - blur(x)^2, 0), REFLECT_101 (rsseg_local_std_f32 without the sqrt). */
-int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out);
+int rsseg_morph_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, int k, int op,
+                        uint8_t *d_out);
 /* 'laplacian' of calculate_filter_responses (indices.py:472-474): cv2.Laplacian(u8, CV_32F) (3x3 cross, REFLECT_101)
- * / 255.0, then (l - min) / (max - min + 1e-10) in float32; the global min / max go through the all-reduce hook. */
+ * / 255.0, then (l - min) / (max - min + 1e-10) in float32.  Two passes over the uint8 plane (extrema, then the
+ * normalised write); the global min / max of the produced rows go through the all-reduce hook. */
 int rsseg_laplacian_norm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out);
+int rsseg_laplacian_norm_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, float *d_out);
 /* sobel_mag (indices.py:477-480): 3x3 Sobel x/y of the uint8 plane as float32 / 255, magnitude,
- * divided by (global max + 1e-10).  Two launches; the global max goes through the all-reduce hook. */
+ * divided by (global max + 1e-10).  Two passes as above; the global max goes through the all-reduce hook. */
 int rsseg_sobel_mag_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out);
+int rsseg_sobel_mag_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, float *d_out);
 
 /* ---- K9/K10: KMeans ------------------------------------------------------------------------ */
 typedef struct rsseg_kmeans_info {
@@ -228,6 +256,13 @@ int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tree_off, cons
 /* predict_image (modules/supervised_classifiers.py:99-115) / supervised_classification_predict
  * (modules/features/extract.py:690-719): d_planes[F] float32 feature planes -> int64 class per pixel. */
 int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes, int F, int64_t n, int64_t *d_out);
+
+/* ---- host-only helper (no GPU needed) ------------------------------------------------------- */
+/* The random draws of k-means++ as the library makes them (numpy RandomState(seed): MT19937, random_sample,
+ * RandomState.choice over n equal weights — sklearn/cluster/_kmeans.py:213-270): *center_id = index of the first
+ * centre, uniforms[(k-1) * (2 + floor(ln k))] = the uniform(size=L) draws of the later rounds.  Used by the CPU test
+ * suite to pin the generator against NumPy. */
+int rsseg_host_kmeans_draws(uint32_t seed, int64_t n, int dtype, int k, int64_t *center_id, double *uniforms);
 
 #ifdef __cplusplus
 }

@@ -393,7 +393,9 @@ def calculate_glcm_features(band, levels=32, window_size=21, step_size=21, mode:
 # stage function   (scripts/2_feature_extraction.py:27-133; only members that reach the stack)
 # --------------------------------------------------------------------------------------------
 def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing=True,
-                                 glcm_window=21, glcm_step=21, glcm_levels=32):
+                                 glcm_window=21, glcm_step=21, glcm_levels=32, pca_fn=None):
+    """scripts/2_feature_extraction.py:27-133.  pca_fn (optional): a perform_pca implementation to use instead of the
+    restatement above (oracle/cpu_harness.py passes the scikit-learn objects for the CPU baseline)."""
     if preprocessing:
         bands_data = [robust_normalize(b) for b in bands_data]
     blue, green, red, nir, swir1 = bands_data[:5]
@@ -405,7 +407,7 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     fd["mndwi"] = calculate_mndwi(green, swir1)
     fd["ndbi"] = calculate_ndbi(swir1, nir)
     fd["bsi"] = calculate_bsi(blue, red, nir, swir1)
-    pca_result, ratio, model = perform_pca([b for b in bands_data if b is not None])
+    pca_result, ratio, model = (pca_fn or perform_pca)([b for b in bands_data if b is not None])
     fd["pca_result"] = pca_result
     fd["variance_ratio"] = ratio
     fd["glcm_features"], _ = calculate_glcm_features(nir, glcm_levels, glcm_window, glcm_step)

@@ -40,6 +40,7 @@ struct rsseg_ctx {
     void *comm_user = nullptr;
     char *d_comm = nullptr;
     size_t comm_bytes = 0;
+    char *h_comm = nullptr;   // pinned staging of the communication buffer (comm_bytes)
     // workspace (device) and pinned host staging
     char *d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -70,6 +70,7 @@ extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
     if (ctx->d_mm) (void)hipFree(ctx->d_mm);
     if (ctx->forest.d_nodes) (void)hipFree(ctx->forest.d_nodes);
     if (ctx->forest.d_leafval) (void)hipFree(ctx->forest.d_leafval);
@@ -92,6 +93,13 @@ extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_all
     ctx->comm_user = user;
     ctx->d_comm = (char *)d_comm;
     ctx->comm_bytes = comm_bytes;
+    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+    ctx->h_comm = nullptr;
+    if (world > 1) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (hipHostMalloc((void **)&ctx->h_comm, comm_bytes, hipHostMallocDefault) != hipSuccess)
+            return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipHostMalloc(%zu) for the communication staging buffer failed", comm_bytes);
+    }
     return RSSEG_OK;
 }
 
@@ -152,12 +160,17 @@ int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, in
     const size_t bytes = esz * (size_t)count;
     if (bytes > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "comm buffer too small (%zu > %zu)", bytes, ctx->comm_bytes);
     const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // ONE host synchronisation per collective: pinned staging -> device buffer (async), the hook enqueues the
+    // collective ordered after the context's stream and leaves its result visible to later work on that stream
+    // (torch.distributed: the collective's stream waits for the current stream, the current stream for the collective),
+    // device buffer -> pinned staging (async), then the single wait.
+    memcpy(ctx->h_comm, host, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_comm, ctx->h_comm, bytes, hipMemcpyHostToDevice, ctx->stream));
     int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
     if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
-    HIPCHK(ctx, hipMemcpyAsync(host, ctx->d_comm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_comm, ctx->d_comm, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->h_comm, bytes);
     if (ctx->prof_on) {  // host wall time of the whole exchange (staging copies + collective), name "allreduce"
         prof_entry &e = ctx->prof["allreduce"];
         e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

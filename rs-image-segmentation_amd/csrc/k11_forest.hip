@@ -283,13 +283,11 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     if (n == 0) return RSSEG_OK;
     const long long *d_classes = (const long long *)fd.d_treeoff;
     const rf_tree *d_trees = (const rf_tree *)((const char *)fd.d_treeoff + fd.n_classes * sizeof(long long));
-    // workgroup size: 1024 pixels (16 waves hide the gathers below the LDS-resident top block) unless the
-    // environment asks for 512 (experiments); LDS = features TH * F * 4 B + two top blocks of ntop 8-byte nodes
-    int TH = 1024;
-    if (const char *e = getenv("RSSEG_FOREST_THREADS")) TH = atoi(e) == 512 ? 512 : (atoi(e) == 256 ? 256 : 1024);
+    // workgroup size: 1024 pixels (16 waves hide the gathers below the LDS-resident top block);
+    // LDS = features TH * F * 4 B + two top blocks of ntop 8-byte nodes
+    const int TH = 1024;
     int ntop = 4096;  // per tree; four blocks resident (two pairs)
     while (ntop > 256 && (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node) > 150 * 1024) ntop >>= 1;
-    if (const char *e = getenv("RSSEG_FOREST_NTOP")) ntop = std::min(ntop, std::max(256, atoi(e)));
     const size_t lds = (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node);
     const unsigned grid = (unsigned)ceil_div64(n, TH);
     auto launch = [&](auto kern) -> int {
@@ -300,8 +298,8 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
         return RSSEG_OK;
     };
     int rc;
-    if (fd.n_classes <= 4) rc = TH == 1024 ? launch(k11_forest<4, 1024>) : (TH == 512 ? launch(k11_forest<4, 512>) : launch(k11_forest<4, 256>));
-    else rc = TH == 1024 ? launch(k11_forest<RF_NCMAX, 1024>) : (TH == 512 ? launch(k11_forest<RF_NCMAX, 512>) : launch(k11_forest<RF_NCMAX, 256>));
+    if (fd.n_classes <= 4) rc = launch(k11_forest<4, 1024>);
+    else rc = launch(k11_forest<RF_NCMAX, 1024>);
     if (rc != RSSEG_OK) return rc;
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

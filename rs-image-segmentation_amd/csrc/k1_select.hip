@@ -168,21 +168,18 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     if (ctx->world > 1 && (size_t)P * hist_bytes > ctx->comm_bytes)
         return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes may need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
 
-    static bool attr_done = false;
-    static int sel_threads = 1024;
+    static bool attr_done[64] = {false};  // hipFuncSetAttribute is per device
     const int SEL_BATCH = 8;  // live prefixes per launch: 8 * (8 KB counters + 2 KB lookup) + 2 KB of LDS
-    if (!attr_done) {
-        const char *ev = getenv("RSSEG_SEL_THREADS");
-        if (ev && atoi(ev) == 256) sel_threads = 256;
+    if (!attr_done[ctx->device & 63]) {
         const int l1 = SEL_BATCH * SEL_BINS * 4 + SEL_BINS, l2 = SEL_BATCH * SEL_BINS * 5 + SEL_BINS, l0 = P0_COPIES * P0_STRIDE * 4;
 #define SEL_ATTR(TH)                                                                                                       \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));    \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));    \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
-        SEL_ATTR(256) SEL_ATTR(1024)
-        attr_done = true;
+        SEL_ATTR(1024)
+        attr_done[ctx->device & 63] = true;
     }
-    const int threads = sel_threads;
+    const int threads = 1024;
     const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
     auto launch = [&](const float *d_x, int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb, unsigned long long *d_nan) {
 #define SEL_GO(PS, TH) hipLaunchKernelGGL((k1_hist<PS, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan)
@@ -192,8 +189,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         else if (pass == 1) SEL_GO(1, TH);   \
         else SEL_GO(2, TH);                  \
     } while (0)
-        if (threads == 256) SEL_PASS(256);
-        else SEL_PASS(1024);
+        SEL_PASS(1024);
     };
     struct plane_state {
         int64_t rem[RSSEG_MAX_RANKS];

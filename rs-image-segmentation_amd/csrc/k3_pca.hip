@@ -17,6 +17,7 @@
 #define PCA_THREADS 256
 #define PCA_MAXB 8
 #define PCA_NACC (PCA_MAXB + PCA_MAXB * (PCA_MAXB + 1) / 2)
+#define PCA_PSTRIDE (2 * PCA_NACC + 2)  // long longs per block in the partial table of k3_gram
 
 struct pca_args {
     const float *band[PCA_MAXB];
@@ -60,6 +61,9 @@ __host__ __device__ constexpr int pca_tri(int b, int c) { return PCA_MAXB + b * 
 template <int NB>
 __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, long long *__restrict__ partial)
 {
+    // partial[blk][2 * PCA_NACC + 2]: the limb sums, then the number of threads that met a NaN (sklearn's PCA rejects
+    // NaN input; a NaN's bit pattern in the integer sums would otherwise pass unnoticed), then padding
+    bool bad = false;
     unsigned long long acc[PCA_NACC];
 #pragma unroll
     for (int i = 0; i < PCA_NACC; i++) acc[i] = 0;
@@ -68,7 +72,10 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
     auto pixel = [&](const float *v) {
         float x[NB];
 #pragma unroll
-        for (int b = 0; b < NB; b++) x[b] = pca_x(a, b, v[b]);
+        for (int b = 0; b < NB; b++) {
+            x[b] = pca_x(a, b, v[b]);
+            bad = bad || x[b] != x[b];
+        }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             acc[b] += (unsigned long long)__double_as_longlong(fma((double)x[b], a.fx_scale, FX_MAGIC));
@@ -108,10 +115,38 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         long long hi = wave_sum(v >> 32), lo = wave_sum(v & 0xffffffffLL);
         if (lane_id() == 0) { sh[threadIdx.x >> 6][2 * i] = hi; sh[threadIdx.x >> 6][2 * i + 1] = lo; }
     }
-    __syncthreads();
+    const int nbad = __syncthreads_count(bad);
     if (threadIdx.x < 2 * PCA_NACC)
-        partial[(size_t)blockIdx.x * 2 * PCA_NACC + threadIdx.x] =
+        partial[(size_t)blockIdx.x * PCA_PSTRIDE + threadIdx.x] =
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * PCA_PSTRIDE + 2 * PCA_NACC] = nbad;
+        partial[(size_t)blockIdx.x * PCA_PSTRIDE + 2 * PCA_NACC + 1] = 0;
+    }
+}
+
+// per-band extrema of the planes as given (NaN ignored): sizes the fixed-point quantum of k3_gram for bands that are not
+// robust-normalised to [0,1].  part[blk][2 * NB] = {min_b, max_b}
+__global__ __launch_bounds__(PCA_THREADS) void k3_range(pca_args a, int64_t off, int64_t n, float *__restrict__ part)
+{
+    __shared__ float sh[4][2 * PCA_MAXB];
+    for (int b = 0; b < a.nb; b++) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCA_THREADS) {
+            const float v = a.band[b][off + i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane_id() == 0) { sh[threadIdx.x >> 6][2 * b] = mn; sh[threadIdx.x >> 6][2 * b + 1] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * a.nb) {
+        const int t = threadIdx.x;
+        const float v0 = sh[0][t], v1 = sh[1][t], v2 = sh[2][t], v3 = sh[3][t];
+        part[(size_t)blockIdx.x * 2 * PCA_MAXB + t] = (t & 1) ? fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) : fminf(fminf(v0, v1), fminf(v2, v3));
+    }
 }
 
 struct proj_args {
@@ -230,17 +265,17 @@ static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][
     for (int i = 0; i < n; i++) w[i] = A[i][i];
 }
 
-static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi, const float *center,
-                    const double *scale, int n_components, float *const *d_out, float *components, float *explained_variance_ratio,
-                    float *mean, float *explained_variance);
+static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
+                    const float *center, const double *scale, int n_components, float *const *d_out, float *components,
+                    float *explained_variance_ratio, float *mean, float *explained_variance);
 
 extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local,
                                            const float *center, const double *scale, int n_components, float *const *d_out,
                                            float *components, float *explained_variance_ratio, float *mean,
                                            float *explained_variance)
 {
-    return pca_core(ctx, d_bands, nb, n_local, nullptr, center, scale, n_components, d_out, components, explained_variance_ratio, mean,
-                    explained_variance);
+    return pca_core(ctx, d_bands, nb, n_local, 0, n_local, nullptr, center, scale, n_components, d_out, components, explained_variance_ratio,
+                    mean, explained_variance);
 }
 
 extern "C" int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi,
@@ -249,13 +284,23 @@ extern "C" int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *cons
                                                float *explained_variance)
 {
     if (ctx && !lohi) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_raw: lohi is required");
-    return pca_core(ctx, d_bands, nb, n_local, lohi, center, scale, n_components, d_out, components, explained_variance_ratio, mean,
-                    explained_variance);
+    return pca_core(ctx, d_bands, nb, n_local, 0, n_local, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
+                    mean, explained_variance);
 }
 
-static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, const float *lohi, const float *center,
-                    const double *scale, int n_components, float *const *d_out, float *components, float *explained_variance_ratio,
-                    float *mean, float *explained_variance)
+extern "C" int rsseg_pca_fit_transform_ext_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off,
+                                               int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
+                                               float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
+                                               float *explained_variance)
+{
+    if (ctx && (fit_off < 0 || fit_n < 0 || fit_off + fit_n > n_local)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_ext: fit range outside the planes");
+    return pca_core(ctx, d_bands, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
+                    mean, explained_variance);
+}
+
+static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
+                    const float *center, const double *scale, int n_components, float *const *d_out, float *components,
+                    float *explained_variance_ratio, float *mean, float *explained_variance)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_bands || nb < 1 || nb > PCA_MAXB || n_components < 1 || n_components > nb || n_local < 0)
@@ -282,50 +327,103 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
         memcpy(&sb, &a.scale[b], 8);
         if (!std::isnormal(a.scale[b]) || !std::isnormal(a.rinv[b]) || (sb & 0xfffffffffffffull) == 0xfffffffffffffull) a.slow_div = 1;
     }
-    // bound on |x'| from the band ranges (one cheap pass would also do; the hot path feeds normalised
-    // bands in [0,1], so bound with that and the scaler): |x'| <= max(|0-c|,|1-c|)/s
+    if (n_local > ((int64_t)1 << 31)) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: more than 2^31 pixels per GPU");
+    // ---- range of the fitted values: robust-normalised bands lie in [0,1] by construction (clip); any other input is
+    // measured (one extra pass over the fitted pixels, extrema all-reduced), so that the fixed-point quantum below fits
+    // whatever the caller passes (raw DN 0-255, reflectances, ...)
+    double vmin[PCA_MAXB], vmax[PCA_MAXB];
+    for (int b = 0; b < nb; b++) { vmin[b] = 0.0; vmax[b] = 1.0; }
+    if (!a.normalise) {
+        const int rgrid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div64(fit_n, PCA_THREADS * 8)));
+        RSCHK(ws_reserve(ctx, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB));
+        RSCHK(pin_reserve(ctx, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB));
+        double mm[2 * PCA_MAXB];
+        for (int b = 0; b < nb; b++) mm[2 * b] = mm[2 * b + 1] = -INFINITY;
+        if (fit_n > 0) {
+            {
+                prof_scope ps(ctx, "gram");
+                hipLaunchKernelGGL(k3_range, dim3(rgrid), dim3(PCA_THREADS), 0, ctx->stream, a, fit_off, fit_n, (float *)ctx->d_ws);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_ws, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            const float *hp = (const float *)ctx->h_pin;
+            for (int g = 0; g < rgrid; g++)
+                for (int b = 0; b < nb; b++) {
+                    mm[2 * b] = std::max(mm[2 * b], -(double)hp[(size_t)g * 2 * PCA_MAXB + 2 * b]);      // MAX-reduce of the negated minimum
+                    mm[2 * b + 1] = std::max(mm[2 * b + 1], (double)hp[(size_t)g * 2 * PCA_MAXB + 2 * b + 1]);
+                }
+        }
+        RSCHK(comm_allreduce_host(ctx, mm, 2 * nb, RSSEG_F64, RSSEG_MAX));
+        for (int b = 0; b < nb; b++) {
+            vmin[b] = -mm[2 * b];
+            vmax[b] = mm[2 * b + 1];
+            if (!(vmin[b] <= vmax[b])) vmin[b] = vmax[b] = 0.0;  // no finite value at all: the NaN check below reports it
+            if (std::isinf(vmin[b]) || std::isinf(vmax[b])) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: Input X contains infinity");
+        }
+    }
     double bound = 1.0;
     for (int b = 0; b < nb; b++) {
         double c = a.scaled ? (double)a.center[b] : 0.0, s = a.scaled ? a.scale[b] : 1.0;
-        bound = std::max(bound, std::max(std::fabs(0.0 - c), std::fabs(1.0 - c)) / s * 1.000001);
+        bound = std::max(bound, std::max(std::fabs(vmin[b] - c), std::fabs(vmax[b] - c)) / std::fabs(s) * 1.000001);
     }
     int e2;
     std::frexp(bound * bound, &e2);           // bound^2 < 2^e2
     const int Q = std::min(38, 48 - e2);      // |x*x| * 2^Q < 2^48: 4096 pixels per thread stay below 2^60
-    if (Q < 8) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: scaled band range too large for exact accumulation (bound %.3g)", bound);
+    if (Q < -40) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: scaled band range too large for exact accumulation (bound %.3g)", bound);
     a.fx_scale = std::ldexp(1.0, Q);
 
-    if (n_local > ((int64_t)1 << 31)) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: more than 2^31 pixels per GPU");
-    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS)));
-    RSCHK(ws_reserve(ctx, sizeof(long long) * (size_t)grid * 2 * PCA_NACC));
-    RSCHK(pin_reserve(ctx, sizeof(long long) * (size_t)grid * 2 * PCA_NACC));
-    long long *d_part = (long long *)ctx->d_ws;
+    // ---- Gram / mean over the fitted pixels [fit_off, fit_off + fit_n): a scalar head up to the first 16-byte
+    // boundary, then the vectorised body
+    struct seg { int64_t off, n; int grid; size_t poff; };
+    seg segs[2];
+    int nseg = 0;
+    size_t pcount = 0;
     {
+        const int64_t head = std::min<int64_t>(fit_n, (4 - (fit_off & 3)) & 3);
+        if (head > 0) { segs[nseg++] = {fit_off, head, 1, pcount}; pcount += PCA_PSTRIDE; }
+        if (fit_n - head > 0) {
+            const int g = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64((fit_n - head) >> 2, PCA_THREADS)));
+            segs[nseg++] = {fit_off + head, fit_n - head, g, pcount};
+            pcount += (size_t)g * PCA_PSTRIDE;
+        }
+    }
+    RSCHK(ws_reserve(ctx, sizeof(long long) * std::max<size_t>(pcount, 1)));
+    RSCHK(pin_reserve(ctx, sizeof(long long) * std::max<size_t>(pcount, 1)));
+    long long *d_part = (long long *)ctx->d_ws;
+    for (int si = 0; si < nseg; si++) {
+        pca_args as = a;
+        for (int b = 0; b < nb; b++) as.band[b] = a.band[b] + segs[si].off;
         prof_scope ps(ctx, "gram");
         switch (nb) {
-#define GRAM_GO(NBV) case NBV: hipLaunchKernelGGL(k3_gram<NBV>, dim3(grid), dim3(PCA_THREADS), 0, ctx->stream, a, n_local, d_part); break;
+#define GRAM_GO(NBV) case NBV: hipLaunchKernelGGL(k3_gram<NBV>, dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff); break;
             GRAM_GO(1) GRAM_GO(2) GRAM_GO(3) GRAM_GO(4) GRAM_GO(5) GRAM_GO(6) GRAM_GO(7) GRAM_GO(8)
 #undef GRAM_GO
         }
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)grid * 2 * PCA_NACC, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pcount) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * pcount, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     typedef __int128 i128;
     long long lim[2 * PCA_NACC + 2];
     {
         const long long *hp = (const long long *)ctx->h_pin;
+        const size_t nblk = pcount / PCA_PSTRIDE;
         for (int i = 0; i < PCA_NACC; i++) {
             i128 s = 0;
-            for (int g = 0; g < grid; g++)
-                s += ((i128)hp[((size_t)g * PCA_NACC + i) * 2] << 32) + (i128)hp[((size_t)g * PCA_NACC + i) * 2 + 1];
+            for (size_t g = 0; g < nblk; g++) s += ((i128)hp[g * PCA_PSTRIDE + 2 * i] << 32) + (i128)hp[g * PCA_PSTRIDE + 2 * i + 1];
             lim[2 * i] = (long long)(s >> 32);
             lim[2 * i + 1] = (long long)(s & 0xffffffffLL);
         }
-        lim[2 * PCA_NACC] = n_local;
-        lim[2 * PCA_NACC + 1] = 0;
+        long long nbad = 0;
+        for (size_t g = 0; g < nblk; g++) nbad += hp[g * PCA_PSTRIDE + 2 * PCA_NACC];
+        lim[2 * PCA_NACC] = fit_n;
+        lim[2 * PCA_NACC + 1] = nbad;
     }
     RSCHK(comm_allreduce_host(ctx, lim, 2 * PCA_NACC + 2, RSSEG_I64, RSSEG_SUM));
+    if (lim[2 * PCA_NACC + 1] != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: Input X contains NaN.");
     const int64_t N = lim[2 * PCA_NACC];
     if (N < 2) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: needs at least 2 samples");
     const double inv = std::ldexp(1.0, -Q);

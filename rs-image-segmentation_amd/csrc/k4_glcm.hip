@@ -535,19 +535,9 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
                 if ((b & 0xfffffffffffffull) == 0xfffffffffffffull) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: window size %d not supported", win);
             }
         }
-        // RSSEG_GLCM_LDS_PAD (experiments): unused dynamic LDS per workgroup, to lower this kernel's occupancy and leave
-        // registers / wave slots to kernels running beside it on another stream
-        static int lds_pad = -1;
-        if (lds_pad < 0) {
-            const char *ev = getenv("RSSEG_GLCM_LDS_PAD");
-            lds_pad = ev ? atoi(ev) : 0;
-            if (lds_pad > 0) {
-                HIPCHK(ctx, hipFuncSetAttribute((const void *)k4_glcm_thread<7, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
-            }
-        }
 #define GLCM_THREAD(WN)                                                                                                           \
     do {                                                                                                                          \
-        if (levels <= 32) hipLaunchKernelGGL((k4_glcm_thread<WN, 3>), tg, dim3(256), (WN == 7 ? lds_pad : 0), ctx->stream, d_q, H, W, step, oh, ow, out, gc); \
+        if (levels <= 32) hipLaunchKernelGGL((k4_glcm_thread<WN, 3>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc); \
         else hipLaunchKernelGGL((k4_glcm_thread<WN, 2>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc);          \
     } while (0)
         if (win == 7) GLCM_THREAD(7);

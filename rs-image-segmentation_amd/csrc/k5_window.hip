@@ -1,18 +1,32 @@
 // K5-K8 — window operators of the level-2 features and of add_spatial_context:
 //   bilinear upsample (cv2.resize INTER_LINEAR, indices.py:308), k x k box mean with float64 sums
-//   (cv2.boxFilter / cv2.blur, indices.py:770-771, 537, 541), local standard deviation
-//   (indices.py:537-548), 5x5 morphological gradient on uint8 (indices.py:422, 433) and 3x3 Sobel
-//   magnitude / global max (indices.py:477-480).  OpenCV semantics as restated in oracle/ref_np.py.
-// All are streaming stencils: one read + one write of the plane (4+4 B/px), HBM-bound; the k x k
-// neighbourhood is served by L1/L2 (row-major 64x4 pixel workgroups).
+//   (cv2.boxFilter / cv2.blur, indices.py:770-771, 537, 541), local variance / standard deviation
+//   (indices.py:537-548), k x k morphology on uint8 (indices.py:421-433), 3x3 Sobel magnitude and Laplacian with
+//   their global extrema (indices.py:472-480).  OpenCV semantics as restated in oracle/ref_np.py.
+//
+// K6-K8 are LDS-tiled separable stencils.  A 256-thread workgroup owns a tile of 256 columns x 32 output rows:
+//   1. the (32 + 2R) x (256 + 8) input tile is staged in LDS with 16-byte loads (border rule applied while loading:
+//      cv2.BORDER_REFLECT, BORDER_REFLECT_101, or edge replication for the morphology, whose out-of-image taps
+//      never win);
+//   2. a thread owns 4 columns x 8 output rows: for each of its 8 + 2R tile rows it reads 12 values (3 x ds_read_b128,
+//      conflict-free), forms the 4 horizontal results of that row (row sums in float64 left to right; running
+//      min / max; Sobel row terms) and keeps the last K rows of them in a register ring; every row from the K-th on
+//      completes one output row (the K ring entries top to bottom) — the summation order fixed in oracle/ref_np.py, so the
+//      float64 box sums stay bit-exact.
+// HBM traffic is the plane once in, once out (halo re-reads are L2 hits); LDS traffic is 1.3 b128 reads per pixel.
+// Rows form: every operator takes a plane of Hin rows and produces rows [y0, y1) of it, so a rank of a row-sharded
+// raster passes its stripe plus R halo rows and gets exactly the rows of the un-sharded result.
 #include <cmath>
 
 #include "common.h"
 
+#define BORDER_REPLICATE 2  // internal: erode / dilate (out-of-image taps never win == replicate the edge)
+
 __device__ __forceinline__ int border_idx(int i, int n, int mode)
 {
-    // mode 0: BORDER_REFLECT (edge duplicated), mode 1: BORDER_REFLECT_101
+    // mode 0: BORDER_REFLECT (edge duplicated), mode 1: BORDER_REFLECT_101, mode 2: replicate
     if (n == 1) return 0;
+    if (mode == BORDER_REPLICATE) return i < 0 ? 0 : (i >= n ? n - 1 : i);
     while (i < 0 || i >= n) {
         if (i < 0) i = mode == 0 ? -i - 1 : -i;
         else i = mode == 0 ? 2 * n - 1 - i : 2 * n - 2 - i;
@@ -23,172 +37,297 @@ __device__ __forceinline__ int border_idx(int i, int n, int mode)
 #define WG_X 64
 #define WG_Y 4
 
+// ---- tile geometry of the LDS stencils ---------------------------------------------------------------------------
+#define TW 256                      // output columns per workgroup
+#define TH 32                       // output rows per workgroup
+#define CPT 4                       // columns per thread
+#define RPT 8                       // output rows per thread
+#define TPAD 4                      // tile columns left / right of the 256 (keeps every LDS read 16-byte aligned)
+#define TSTRIDE (TW + 2 * TPAD)     // elements per tile row
+#define WIN_MAXP 8
+
+struct win_planes {
+    const void *in[WIN_MAXP];
+    void *out[WIN_MAXP];
+};
+
+template <typename E> struct vec4;
+template <> struct vec4<float> { typedef float4 type; };
+template <> struct vec4<uint8_t> { typedef uint32_t type; };
+
+// tile[(TH + 2R)][TSTRIDE]: tile row r holds input row border(yb - R + r), tile column c input column x0 - TPAD + c
+// (columns further than R outside the image are never read by the stencil and are left zero)
+template <typename E, int R>
+__device__ __forceinline__ void load_tile(E *__restrict__ tile, const E *__restrict__ x, int Hin, int W, int mode, int x0, int yb)
+{
+    typedef typename vec4<E>::type V;
+    constexpr int NR = TH + 2 * R, SLOTS = TSTRIDE / 4;
+    const bool vec = (W & 3) == 0 && ((uintptr_t)x & (sizeof(V) - 1)) == 0;
+    for (int s = threadIdx.x; s < NR * SLOTS; s += 256) {
+        const int r = s / SLOTS, g = s - r * SLOTS;
+        const int gc = x0 - TPAD + 4 * g;
+        const E *row = x + (size_t)border_idx(yb - R + r, Hin, mode) * W;
+        V v;
+        if (vec && gc >= 0 && gc + 3 < W) {
+            v = *reinterpret_cast<const V *>(row + gc);
+        } else {
+            E e[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = gc + q;
+                e[q] = (c < -R || c >= W + R) ? (E)0 : row[border_idx(c, W, mode)];
+            }
+            memcpy(&v, e, sizeof(V));
+        }
+        *reinterpret_cast<V *>(tile + r * TSTRIDE + 4 * g) = v;
+    }
+}
+
+__device__ __forceinline__ void read12(const float *p, float (&v)[12])
+{
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1], c = reinterpret_cast<const float4 *>(p)[2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ __forceinline__ void read12(const uint8_t *p, int (&v)[12])
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t a = w[0], b = w[1], c = w[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        v[q] = (a >> (8 * q)) & 255u;
+        v[4 + q] = (b >> (8 * q)) & 255u;
+        v[8 + q] = (c >> (8 * q)) & 255u;
+    }
+}
+
+__device__ __forceinline__ void store4(float *out, int W, int orow, int col, const float (&o)[4], bool vec)
+{
+    float *p = out + (size_t)orow * W + col;
+    if (vec) *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (col + q < W) p[q] = o[q];
+}
+__device__ __forceinline__ void store4(uint8_t *out, int W, int orow, int col, const int (&o)[4], bool vec)
+{
+    uint8_t *p = out + (size_t)orow * W + col;
+    if (vec) *reinterpret_cast<uint32_t *>(p) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+    else
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (col + q < W) p[q] = (uint8_t)o[q];
+}
+
 // ---- box mean (optionally of x*x), float64 sums: rows left-to-right, then rows top-to-bottom ----
-template <int K>
-__global__ __launch_bounds__(256) void k6_box(const float *__restrict__ x, int H, int W, int mode, int square, float *__restrict__ out)
+template <int K, bool SQ>
+__global__ __launch_bounds__(256) void k6_box(win_planes pl, int Hin, int W, int y0, int nrows, int mode)
 {
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
     constexpr int R = K / 2;
-    int xs[K];
+    __shared__ __align__(16) float tile[(TH + 2 * R) * TSTRIDE];
+    const float *x = (const float *)pl.in[blockIdx.z];
+    float *out = (float *)pl.out[blockIdx.z];
+    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    load_tile<float, R>(tile, x, Hin, W, mode, x0, y0 + ty0);
+    __syncthreads();
+    const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
+    if (x0 + cx >= W || ty0 + ry >= nrows) return;
+    const bool vec = (W & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    double ring[K][CPT];
 #pragma unroll
-    for (int d = 0; d < K; d++) xs[d] = border_idx(px + d - R, W, mode);
-    double acc = 0.0;
+    for (int j = 0; j < RPT + 2 * R; j++) {
+        float v[12];
+        read12(tile + (ry + j) * TSTRIDE + cx, v);
+        if (SQ)
 #pragma unroll
-    for (int dy = 0; dy < K; dy++) {
-        const float *row = x + (size_t)border_idx(py + dy - R, H, mode) * W;
-        double rs = 0.0;
+            for (int e = 0; e < 12; e++) v[e] = v[e] * v[e];
 #pragma unroll
-        for (int d = 0; d < K; d++) {
-            float v = row[xs[d]];
-            if (square) v = v * v;
-            rs = d == 0 ? (double)v : rs + (double)v;
+        for (int c = 0; c < CPT; c++) {
+            double rs = (double)v[TPAD - R + c];
+#pragma unroll
+            for (int d = 1; d < K; d++) rs = rs + (double)v[TPAD - R + c + d];
+            ring[j % K][c] = rs;
         }
-        acc = dy == 0 ? rs : acc + rs;
+        if (j >= 2 * R) {
+            const int i = j - 2 * R, orow = ty0 + ry + i;
+            if (orow < nrows) {
+                float o[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    double acc = ring[i % K][c];
+#pragma unroll
+                    for (int dy = 1; dy < K; dy++) acc = acc + ring[(i + dy) % K][c];
+                    o[c] = (float)(acc * (1.0 / (double)(K * K)));
+                }
+                store4(out, W, orow, x0 + cx, o, vec);
+            }
+        }
     }
-    out[(size_t)py * W + px] = (float)(acc * (1.0 / (double)(K * K)));
 }
 
+// variance_scale_k / std_dev_scale_k: max(blur(x*x) - blur(x)^2, 0) [sqrt], BORDER_REFLECT_101 (indices.py:537-548)
 template <int K, bool VAR>
-__global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int H, int W, float *__restrict__ out)
+__global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int Hin, int W, int y0, int nrows, float *__restrict__ out)
 {
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
     constexpr int R = K / 2;
-    int xs[K];
-#pragma unroll
-    for (int d = 0; d < K; d++) xs[d] = border_idx(px + d - R, W, 1);
-    double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-    for (int dy = 0; dy < K; dy++) {
-        const float *row = x + (size_t)border_idx(py + dy - R, H, 1) * W;
-        double r1 = 0.0, r2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < K; d++) {
-            const float v = row[xs[d]];
-            const float vv = v * v;
-            r1 = d == 0 ? (double)v : r1 + (double)v;
-            r2 = d == 0 ? (double)vv : r2 + (double)vv;
-        }
-        a1 = dy == 0 ? r1 : a1 + r1;
-        a2 = dy == 0 ? r2 : a2 + r2;
-    }
+    __shared__ __align__(16) float tile[(TH + 2 * R) * TSTRIDE];
+    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    load_tile<float, R>(tile, x, Hin, W, 1, x0, y0 + ty0);
+    __syncthreads();
+    const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
+    if (x0 + cx >= W || ty0 + ry >= nrows) return;
+    const bool vec = (W & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    double ring1[K][CPT], ring2[K][CPT];
     const double sc = 1.0 / (double)(K * K);
-    const float mean = (float)(a1 * sc), mean_sq = (float)(a2 * sc);
-    const float mm = mean * mean;
-    float var = mean_sq - mm;
-    if (var < 0.f) var = 0.f;
-    out[(size_t)py * W + px] = VAR ? var : sqrtf(var);
-}
-
-template <int K>
-__global__ __launch_bounds__(256) void k7_morph_grad(const uint8_t *__restrict__ q, int H, int W, uint8_t *__restrict__ out)
-{
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
-    constexpr int R = K / 2;
-    int mn = 255, mx = 0;
 #pragma unroll
-    for (int dy = -R; dy <= R; dy++) {
-        const int yy = py + dy;
-        if (yy < 0 || yy >= H) continue;
+    for (int j = 0; j < RPT + 2 * R; j++) {
+        float v[12], vv[12];
+        read12(tile + (ry + j) * TSTRIDE + cx, v);
 #pragma unroll
-        for (int dx = -R; dx <= R; dx++) {
-            const int xx = px + dx;
-            if (xx < 0 || xx >= W) continue;
-            const int v = q[(size_t)yy * W + xx];
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
+        for (int e = 0; e < 12; e++) vv[e] = v[e] * v[e];
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            double r1 = (double)v[TPAD - R + c], r2 = (double)vv[TPAD - R + c];
+#pragma unroll
+            for (int d = 1; d < K; d++) {
+                r1 = r1 + (double)v[TPAD - R + c + d];
+                r2 = r2 + (double)vv[TPAD - R + c + d];
+            }
+            ring1[j % K][c] = r1;
+            ring2[j % K][c] = r2;
+        }
+        if (j >= 2 * R) {
+            const int i = j - 2 * R, orow = ty0 + ry + i;
+            if (orow < nrows) {
+                float o[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    double a1 = ring1[i % K][c], a2 = ring2[i % K][c];
+#pragma unroll
+                    for (int dy = 1; dy < K; dy++) {
+                        a1 = a1 + ring1[(i + dy) % K][c];
+                        a2 = a2 + ring2[(i + dy) % K][c];
+                    }
+                    const float mean = (float)(a1 * sc), mean_sq = (float)(a2 * sc);
+                    const float mm = mean * mean;
+                    float var = mean_sq - mm;
+                    if (var < 0.f) var = 0.f;
+                    o[c] = VAR ? var : sqrtf(var);
+                }
+                store4(out, W, orow, x0 + cx, o, vec);
+            }
         }
     }
-    out[(size_t)py * W + px] = (uint8_t)(mx - mn);
 }
 
-// erode (MODE 0: min) / dilate (MODE 1: max) with a K x K rectangle; taps outside the image never win
+// erode (MODE 0: min), dilate (MODE 1: max), gradient (MODE 2: max - min) with a K x K rectangle
 template <int K, int MODE>
-__global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, int H, int W, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, int Hin, int W, int y0, int nrows, uint8_t *__restrict__ out)
 {
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
     constexpr int R = K / 2;
-    int acc = MODE == 0 ? 255 : 0;
+    __shared__ __align__(16) uint8_t tile[(TH + 2 * R) * TSTRIDE];
+    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    load_tile<uint8_t, R>(tile, q, Hin, W, BORDER_REPLICATE, x0, y0 + ty0);
+    __syncthreads();
+    const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
+    if (x0 + cx >= W || ty0 + ry >= nrows) return;
+    const bool vec = (W & 3) == 0 && ((uintptr_t)out & 3) == 0;
+    int rmin[K][CPT], rmax[K][CPT];
 #pragma unroll
-    for (int dy = -R; dy <= R; dy++) {
-        const int yy = py + dy;
-        if (yy < 0 || yy >= H) continue;
+    for (int j = 0; j < RPT + 2 * R; j++) {
+        int v[12];
+        read12(tile + (ry + j) * TSTRIDE + cx, v);
 #pragma unroll
-        for (int dx = -R; dx <= R; dx++) {
-            const int xx = px + dx;
-            if (xx < 0 || xx >= W) continue;
-            const int v = q[(size_t)yy * W + xx];
-            acc = MODE == 0 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+        for (int c = 0; c < CPT; c++) {
+            int mn = v[TPAD - R + c], mx = mn;
+#pragma unroll
+            for (int d = 1; d < K; d++) {
+                const int t = v[TPAD - R + c + d];
+                if (MODE != 1) mn = t < mn ? t : mn;
+                if (MODE != 0) mx = t > mx ? t : mx;
+            }
+            rmin[j % K][c] = mn;
+            rmax[j % K][c] = mx;
+        }
+        if (j >= 2 * R) {
+            const int i = j - 2 * R, orow = ty0 + ry + i;
+            if (orow < nrows) {
+                int o[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; c++) {
+                    int mn = rmin[i % K][c], mx = rmax[i % K][c];
+#pragma unroll
+                    for (int dy = 1; dy < K; dy++) {
+                        const int a = rmin[(i + dy) % K][c], b = rmax[(i + dy) % K][c];
+                        if (MODE != 1) mn = a < mn ? a : mn;
+                        if (MODE != 0) mx = b > mx ? b : mx;
+                    }
+                    o[c] = MODE == 0 ? mn : (MODE == 1 ? mx : mx - mn);
+                }
+                store4(out, W, orow, x0 + cx, o, vec);
+            }
         }
     }
-    out[(size_t)py * W + px] = (uint8_t)acc;
 }
 
-// cv2.Laplacian(u8, CV_32F), aperture 1: cross stencil, BORDER_REFLECT_101; value / 255 in float32.
-// blockmin/blockmax[blk] = extrema over the block (for the min-max normalisation that follows)
-__global__ __launch_bounds__(256) void k8_laplace(const uint8_t *__restrict__ q, int H, int W, float *__restrict__ out,
-                                                  float *__restrict__ blockmin, float *__restrict__ blockmax)
+// 3x3 Sobel magnitude (KIND 0) and cross Laplacian (KIND 1) of a uint8 plane, BORDER_REFLECT_101, value / 255 in float32.
+// PASS 0 reduces the extrema of the rows [y0, y0 + nrows) into mm[0..1] (ordered keys, common.h) and writes nothing;
+// PASS 1 recomputes the stencil and writes (value - sub) / den — the plane is read twice (1 B/px each) and written
+// once instead of being written, re-read and re-written as float32.
+template <int KIND, int PASS>
+__global__ __launch_bounds__(256) void k8_filter(const uint8_t *__restrict__ q, int Hin, int W, int y0, int nrows, float *__restrict__ out,
+                                                 float sub, float den, uint32_t *__restrict__ mm)
 {
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    float l = 0.f;
-    const bool live = px < W && py < H;
-    if (live) {
-        const int xm = border_idx(px - 1, W, 1), xp = border_idx(px + 1, W, 1);
-        const int ym = border_idx(py - 1, H, 1), yp = border_idx(py + 1, H, 1);
-        const int c = q[(size_t)py * W + px];
-        const int s = (int)q[(size_t)ym * W + px] + (int)q[(size_t)yp * W + px] + (int)q[(size_t)py * W + xm] + (int)q[(size_t)py * W + xp] - 4 * c;
-        l = (float)s / 255.0f;
-        out[(size_t)py * W + px] = l;
-    }
-    float mn = wave_min(live ? l : INFINITY), mx = wave_max(live ? l : -INFINITY);
-    __shared__ float smn[4], smx[4];
-    if (lane_id() == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    constexpr int R = 1;
+    __shared__ __align__(16) uint8_t tile[(TH + 2 * R) * TSTRIDE];
+    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    load_tile<uint8_t, R>(tile, q, Hin, W, 1, x0, y0 + ty0);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        blockmin[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-        blockmax[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
+    float lmn = INFINITY, lmx = -INFINITY;
+    if (x0 + cx < W && ty0 + ry < nrows) {
+        const bool vec = (W & 3) == 0 && ((uintptr_t)out & 15) == 0;
+        int ra[3][CPT], rb[3][CPT];  // Sobel: horizontal difference / smoothing of a row; Laplacian: left + right / centre
+#pragma unroll
+        for (int j = 0; j < RPT + 2; j++) {
+            int v[12];
+            read12(tile + (ry + j) * TSTRIDE + cx, v);
+#pragma unroll
+            for (int c = 0; c < CPT; c++) {
+                const int l = v[3 + c], m = v[4 + c], r = v[5 + c];
+                ra[j % 3][c] = KIND == 0 ? r - l : l + r;
+                rb[j % 3][c] = KIND == 0 ? l + 2 * m + r : m;
+            }
+            if (j >= 2) {
+                const int i = j - 2, orow = ty0 + ry + i;
+                if (orow < nrows) {
+                    float o[CPT];
+#pragma unroll
+                    for (int c = 0; c < CPT; c++) {
+                        float val;
+                        if (KIND == 0) {
+                            const int gx = ra[i % 3][c] + 2 * ra[(i + 1) % 3][c] + ra[(i + 2) % 3][c];
+                            const int gy = rb[(i + 2) % 3][c] - rb[i % 3][c];
+                            const float sx = (float)gx / 255.0f, sy = (float)gy / 255.0f;
+                            const float s2 = sx * sx + sy * sy;
+                            val = sqrtf(s2);
+                        } else {
+                            const int s = rb[i % 3][c] + rb[(i + 2) % 3][c] + ra[(i + 1) % 3][c] - 4 * rb[(i + 1) % 3][c];
+                            val = (float)s / 255.0f;
+                        }
+                        if (PASS == 0) {
+                            if (x0 + cx + c < W) { lmn = fminf(lmn, val); lmx = fmaxf(lmx, val); }
+                        } else {
+                            const float dlt = val - sub;
+                            o[c] = KIND == 0 ? val / den : dlt / den;
+                        }
+                    }
+                    if (PASS == 1) store4(out, W, orow, x0 + cx, o, vec);
+                }
+            }
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void k8_sub_div(float *__restrict__ x, int64_t n, float sub, float den)
-{
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float d = x[i] - sub;
-        x[i] = d / den;
-    }
-}
-
-// Sobel magnitude; blockmax[blk] = max over the block
-__global__ __launch_bounds__(256) void k8_sobel(const uint8_t *__restrict__ q, int H, int W, float *__restrict__ out,
-                                                float *__restrict__ blockmax)
-{
-    const int px = blockIdx.x * WG_X + (threadIdx.x & 63), py = blockIdx.y * WG_Y + (threadIdx.x >> 6);
-    float mag = 0.f;
-    if (px < W && py < H) {
-        const int xm = border_idx(px - 1, W, 1), xp = border_idx(px + 1, W, 1);
-        const int ym = border_idx(py - 1, H, 1), yp = border_idx(py + 1, H, 1);
-        const uint8_t *r0 = q + (size_t)ym * W, *r1 = q + (size_t)py * W, *r2 = q + (size_t)yp * W;
-        const int a = r0[xm], b = r0[px], c = r0[xp], d = r1[xm], f = r1[xp], g = r2[xm], h = r2[px], i = r2[xp];
-        const int gx = (c - a) + 2 * (f - d) + (i - g);
-        const int gy = (g - a) + 2 * (h - b) + (i - c);
-        const float sx = (float)gx / 255.0f, sy = (float)gy / 255.0f;
-        const float s2 = sx * sx + sy * sy;
-        mag = sqrtf(s2);
-        out[(size_t)py * W + px] = mag;
-    }
-    float m = wave_max(mag);
-    __shared__ float sm[4];
-    if (lane_id() == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) blockmax[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-}
-
-__global__ __launch_bounds__(256) void k8_div(float *__restrict__ x, int64_t n, float den)
-{
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = x[i] / den;
+    if (PASS == 0) mm_commit(mm, lmn, lmx);  // lanes without pixels carry +inf / -inf: they never win
 }
 
 // cv2.resize INTER_LINEAR float32: horizontal taps (edge taps get weight 0), vertical taps clamp rows
@@ -245,22 +384,74 @@ __global__ __launch_bounds__(256) void k5_resize(const float *__restrict__ src, 
 }
 
 static dim3 grid2d(int H, int W) { return dim3((W + WG_X - 1) / WG_X, (H + WG_Y - 1) / WG_Y); }
+static dim3 tile_grid(int nrows, int W, int nplanes = 1) { return dim3((W + TW - 1) / TW, (nrows + TH - 1) / TH, nplanes); }
+
+// rows form: the plane holds Hin rows; rows [y0, y1) are produced.  edges bit 0 / bit 1: row 0 / row Hin - 1 is the
+// image's first / last row (the border rule applies there); otherwise it is a halo row of a stripe and must be out of
+// the stencil's reach
+static int rows_check(rsseg_ctx *ctx, const char *what, const void *in, const void *out, int Hin, int W, int y0, int y1, int R, int edges)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!in || !out || Hin < 1 || W < 1 || y0 < 0 || y1 > Hin || y0 > y1) return rs_fail(ctx, RSSEG_ERR_INVALID, "%s: bad arguments", what);
+    if (in == out) return rs_fail(ctx, RSSEG_ERR_INVALID, "%s: in-place not supported", what);
+    if (y0 < y1 && ((!(edges & 1) && y0 < R) || (!(edges & 2) && y1 + R > Hin)))
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "%s: rows [%d,%d) of a %d-row stripe need %d halo rows on a side that is not an image edge", what, y0, y1, Hin, R);
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_box_mean_rows_f32(rsseg_ctx *ctx, const float *const *d_x, int nplanes, int Hin, int W, int y0, int y1, int edges, int k,
+                                       int border, int square, float *const *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_out || nplanes < 1 || nplanes > WIN_MAXP || (border != 0 && border != 1)) return rs_fail(ctx, RSSEG_ERR_INVALID, "box_mean: bad arguments");
+    if (k != 3 && k != 5 && k != 7 && k != 9) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "box_mean: kernel size %d not in {3,5,7,9}", k);
+    win_planes pl;
+    memset(&pl, 0, sizeof(pl));
+    for (int p = 0; p < nplanes; p++) {
+        RSCHK(rows_check(ctx, "box_mean", d_x[p], d_out[p], Hin, W, y0, y1, k / 2, edges));
+        pl.in[p] = d_x[p];
+        pl.out[p] = d_out[p];
+    }
+    if (y0 == y1) return RSSEG_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, nplanes > 1 ? "ctxmean" : "box");  // "ctxmean": several planes per launch (add_spatial_context)
+        const dim3 g = tile_grid(y1 - y0, W, nplanes);
+#define BOX_GO(KV)                                                                                                      \
+    case KV:                                                                                                            \
+        if (square) hipLaunchKernelGGL((k6_box<KV, true>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border); \
+        else hipLaunchKernelGGL((k6_box<KV, false>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border);      \
+        break;
+        switch (k) { BOX_GO(3) BOX_GO(5) BOX_GO(7) BOX_GO(9) }
+#undef BOX_GO
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
 
 extern "C" int rsseg_box_mean_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, int border, int square, float *d_out)
 {
+    return rsseg_box_mean_rows_f32(ctx, &d_x, 1, H, W, 0, H, 3, k, border, square, &d_out);
+}
+
+extern "C" int rsseg_local_std_rows_f32(rsseg_ctx *ctx, const float *d_x, int Hin, int W, int y0, int y1, int edges, int k, int variance,
+                                        float *d_out)
+{
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_x || !d_out || H < 1 || W < 1 || (border != 0 && border != 1)) return rs_fail(ctx, RSSEG_ERR_INVALID, "box_mean: bad arguments");
-    if (d_x == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "box_mean: in-place not supported");
+    if (k != 3 && k != 5 && k != 7) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "local_std: kernel size %d not in {3,5,7}", k);
+    RSCHK(rows_check(ctx, "local_std", d_x, d_out, Hin, W, y0, y1, k / 2, edges));
+    if (y0 == y1) return RSSEG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         prof_scope ps(ctx, "box");
-        switch (k) {
-        case 3: hipLaunchKernelGGL(k6_box<3>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, border, square, d_out); break;
-        case 5: hipLaunchKernelGGL(k6_box<5>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, border, square, d_out); break;
-        case 7: hipLaunchKernelGGL(k6_box<7>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, border, square, d_out); break;
-        case 9: hipLaunchKernelGGL(k6_box<9>, grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, border, square, d_out); break;
-        default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "box_mean: kernel size %d not in {3,5,7,9}", k);
-        }
+        const dim3 g = tile_grid(y1 - y0, W);
+#define STD_GO(KV)                                                                                                \
+    case KV:                                                                                                      \
+        if (variance) hipLaunchKernelGGL((k6_std<KV, true>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out); \
+        else hipLaunchKernelGGL((k6_std<KV, false>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out);         \
+        break;
+        switch (k) { STD_GO(3) STD_GO(5) STD_GO(7) }
+#undef STD_GO
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
@@ -268,157 +459,139 @@ extern "C" int rsseg_box_mean_f32(rsseg_ctx *ctx, const float *d_x, int H, int W
 
 extern "C" int rsseg_local_std_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out)
 {
-    if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_x || !d_out || H < 1 || W < 1 || d_x == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "local_std: bad arguments");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    {
-        prof_scope ps(ctx, "box");
-        switch (k) {
-        case 3: hipLaunchKernelGGL((k6_std<3, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 5: hipLaunchKernelGGL((k6_std<5, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 7: hipLaunchKernelGGL((k6_std<7, false>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "local_std: kernel size %d not in {3,5,7}", k);
-        }
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return stream_sync(ctx);
-}
-
-extern "C" int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, uint8_t *d_out)
-{
-    if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_q || !d_out || H < 1 || W < 1 || d_q == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "morph_gradient: bad arguments");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    {
-        prof_scope ps(ctx, "stencil");
-        switch (k) {
-        case 3: hipLaunchKernelGGL(k7_morph_grad<3>, grid2d(H, W), dim3(256), 0, ctx->stream, d_q, H, W, d_out); break;
-        case 5: hipLaunchKernelGGL(k7_morph_grad<5>, grid2d(H, W), dim3(256), 0, ctx->stream, d_q, H, W, d_out); break;
-        case 7: hipLaunchKernelGGL(k7_morph_grad<7>, grid2d(H, W), dim3(256), 0, ctx->stream, d_q, H, W, d_out); break;
-        default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph_gradient: kernel size %d not in {3,5,7}", k);
-        }
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return stream_sync(ctx);
+    return rsseg_local_std_rows_f32(ctx, d_x, H, W, 0, H, 3, k, 0, d_out);
 }
 
 extern "C" int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int W, int k, float *d_out)
 {
-    if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_x || !d_out || H < 1 || W < 1 || d_x == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "local_var: bad arguments");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    {
-        prof_scope ps(ctx, "box");
-        switch (k) {
-        case 3: hipLaunchKernelGGL((k6_std<3, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 5: hipLaunchKernelGGL((k6_std<5, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        case 7: hipLaunchKernelGGL((k6_std<7, true>), grid2d(H, W), dim3(256), 0, ctx->stream, d_x, H, W, d_out); break;
-        default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "local_var: kernel size %d not in {3,5,7}", k);
-        }
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return stream_sync(ctx);
+    return rsseg_local_std_rows_f32(ctx, d_x, H, W, 0, H, 3, k, 1, d_out);
 }
 
-template <int MODE> static int morph_launch(rsseg_ctx *ctx, const uint8_t *in, int H, int W, int k, uint8_t *out)
+template <int MODE> static int morph_launch(rsseg_ctx *ctx, const uint8_t *in, int Hin, int W, int y0, int y1, int k, uint8_t *out)
 {
-    prof_scope ps(ctx, "stencil");
+    prof_scope ps(ctx, "morph");
+    const dim3 g = tile_grid(y1 - y0, W);
     switch (k) {
-    case 3: hipLaunchKernelGGL((k7_morph<3, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
-    case 5: hipLaunchKernelGGL((k7_morph<5, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
-    case 7: hipLaunchKernelGGL((k7_morph<7, MODE>), grid2d(H, W), dim3(256), 0, ctx->stream, in, H, W, out); break;
-    default: return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph: kernel size %d not in {3,5,7}", k);
+    case 3: hipLaunchKernelGGL((k7_morph<3, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
+    case 5: hipLaunchKernelGGL((k7_morph<5, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
+    case 7: hipLaunchKernelGGL((k7_morph<7, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
     }
     return RSSEG_OK;
 }
 
-extern "C" int rsseg_morph_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out)
+extern "C" int rsseg_morph_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, int k, int op, uint8_t *d_out)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_q || !d_out || H < 1 || W < 1 || d_q == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "morph: bad arguments");
-    if (op == RSSEG_MORPH_GRADIENT) return rsseg_morph_gradient_u8(ctx, d_q, H, W, k, d_out);
+    if (k != 3 && k != 5 && k != 7) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph: kernel size %d not in {3,5,7}", k);
+    const int R = k / 2;
+    const bool two = op == RSSEG_MORPH_OPEN || op == RSSEG_MORPH_CLOSE;
+    if (op < RSSEG_MORPH_ERODE || op > RSSEG_MORPH_GRADIENT) return rs_fail(ctx, RSSEG_ERR_INVALID, "morph: unknown operation %d", op);
+    RSCHK(rows_check(ctx, "morph", d_q, d_out, Hin, W, y0, y1, two ? 2 * R : R, edges));
+    if (y0 == y1) return RSSEG_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (op == RSSEG_MORPH_ERODE) RSCHK(morph_launch<0>(ctx, d_q, H, W, k, d_out));
-    else if (op == RSSEG_MORPH_DILATE) RSCHK(morph_launch<1>(ctx, d_q, H, W, k, d_out));
-    else if (op == RSSEG_MORPH_OPEN || op == RSSEG_MORPH_CLOSE) {
-        RSCHK(ws_reserve(ctx, (size_t)H * W));
+    if (op == RSSEG_MORPH_ERODE) RSCHK(morph_launch<0>(ctx, d_q, Hin, W, y0, y1, k, d_out));
+    else if (op == RSSEG_MORPH_DILATE) RSCHK(morph_launch<1>(ctx, d_q, Hin, W, y0, y1, k, d_out));
+    else if (op == RSSEG_MORPH_GRADIENT) RSCHK(morph_launch<2>(ctx, d_q, Hin, W, y0, y1, k, d_out));
+    else {
+        // first pass on rows [t0, t1) = [y0 - R, y1 + R) clipped to the plane (a clipped side is an image edge by
+        // rows_check), second pass on that intermediate: its rows outside [y0 - R, y1 + R) are never tapped
+        const int t0 = std::max(y0 - R, 0), t1 = std::min(y1 + R, Hin);
+        RSCHK(ws_reserve(ctx, (size_t)(t1 - t0) * W + 64));
         uint8_t *tmp = (uint8_t *)ctx->d_ws;
         if (op == RSSEG_MORPH_OPEN) {
-            RSCHK(morph_launch<0>(ctx, d_q, H, W, k, tmp));
-            RSCHK(morph_launch<1>(ctx, tmp, H, W, k, d_out));
+            RSCHK(morph_launch<0>(ctx, d_q, Hin, W, t0, t1, k, tmp));
+            RSCHK(morph_launch<1>(ctx, tmp, t1 - t0, W, y0 - t0, y1 - t0, k, d_out));
         } else {
-            RSCHK(morph_launch<1>(ctx, d_q, H, W, k, tmp));
-            RSCHK(morph_launch<0>(ctx, tmp, H, W, k, d_out));
+            RSCHK(morph_launch<1>(ctx, d_q, Hin, W, t0, t1, k, tmp));
+            RSCHK(morph_launch<0>(ctx, tmp, t1 - t0, W, y0 - t0, y1 - t0, k, d_out));
         }
-    } else
-        return rs_fail(ctx, RSSEG_ERR_INVALID, "morph: unknown operation %d", op);
+    }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
 }
 
-extern "C" int rsseg_laplacian_norm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out)
+extern "C" int rsseg_morph_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out)
 {
-    if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_q || !d_out || H < 1 || W < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "laplacian: bad arguments");
+    return rsseg_morph_rows_u8(ctx, d_q, H, W, 0, H, 3, k, op, d_out);
+}
+
+extern "C" int rsseg_morph_gradient_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, uint8_t *d_out)
+{
+    return rsseg_morph_rows_u8(ctx, d_q, H, W, 0, H, 3, k, RSSEG_MORPH_GRADIENT, d_out);
+}
+
+// Sobel magnitude / Laplacian: extrema pass, all-reduce of the two scalars, normalising write pass
+template <int KIND>
+static int filter_rows(rsseg_ctx *ctx, const char *what, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, float *d_out)
+{
+    RSCHK(rows_check(ctx, what, d_q, d_out, Hin, W, y0, y1, 1, edges));
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const dim3 g = grid2d(H, W);
-    const size_t nb = (size_t)g.x * g.y;
-    RSCHK(ws_reserve(ctx, 2 * nb * sizeof(float)));
-    RSCHK(pin_reserve(ctx, 2 * nb * sizeof(float)));
-    {
-        prof_scope ps(ctx, "stencil");
-        hipLaunchKernelGGL(k8_laplace, g, dim3(256), 0, ctx->stream, d_q, H, W, d_out, (float *)ctx->d_ws, (float *)ctx->d_ws + nb);
+    RSCHK(ws_reserve(ctx, 256));
+    RSCHK(pin_reserve(ctx, 256));
+    uint32_t *d_keys = (uint32_t *)ctx->d_ws;
+    const dim3 g = tile_grid(std::max(y1 - y0, 1), W);
+    double mm[2] = {-INFINITY, -INFINITY};  // {-(min), max}: a rank without rows contributes nothing to the MAX-reduce
+    if (y1 > y0) {
+        HIPCHK(ctx, hipMemsetAsync(d_keys, 0xff, 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_keys + 1, 0, 4, ctx->stream));
+        {
+            prof_scope ps(ctx, "filt_max");
+            hipLaunchKernelGGL((k8_filter<KIND, 0>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, (float *)nullptr, 0.f, 1.f, d_keys);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_keys, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        auto unkey = [](uint32_t key) {
+            uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+            float f;
+            memcpy(&f, &u, 4);
+            return (double)f;
+        };
+        mm[0] = -unkey(((const uint32_t *)ctx->h_pin)[0]);
+        mm[1] = unkey(((const uint32_t *)ctx->h_pin)[1]);
     }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_ws, 2 * nb * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    float mn = INFINITY, mx = -INFINITY;
-    for (size_t i = 0; i < nb; i++) {
-        mn = std::min(mn, ((const float *)ctx->h_pin)[i]);
-        mx = std::max(mx, ((const float *)ctx->h_pin)[nb + i]);
-    }
-    double mm[2] = {-(double)mn, (double)mx};  // MAX-reduce of the negated minimum
     RSCHK(comm_allreduce_host(ctx, mm, 2, RSSEG_F64, RSSEG_MAX));
+    if (y1 == y0) return RSSEG_OK;
     volatile float fmn = (float)(-mm[0]), fmx = (float)mm[1];
-    volatile float range = fmx - fmn;
-    volatile float den = range + 1e-10f;  // float32 throughout (NumPy 2 weak-scalar promotion)
+    float sub, den;
+    if (KIND == 0) {  // sobel_mag / (sobel_mag.max() + 1e-10), float32 (indices.py:480)
+        volatile float d = fmx + 1e-10f;
+        sub = 0.f;
+        den = d;
+    } else {          // (l - min) / (max - min + 1e-10), float32 throughout (indices.py:474)
+        volatile float range = fmx - fmn;
+        volatile float d = range + 1e-10f;
+        sub = fmn;
+        den = d;
+    }
     {
-        prof_scope ps(ctx, "stencil");
-        hipLaunchKernelGGL(k8_sub_div, dim3((unsigned)std::min<int64_t>(2048, ceil_div64((int64_t)H * W, 256))), dim3(256), 0, ctx->stream,
-                           d_out, (int64_t)H * W, (float)fmn, (float)den);
+        prof_scope ps(ctx, "filt_write");
+        hipLaunchKernelGGL((k8_filter<KIND, 1>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, d_out, sub, den, (uint32_t *)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
+}
+
+extern "C" int rsseg_sobel_mag_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    return filter_rows<0>(ctx, "sobel_mag", d_q, Hin, W, y0, y1, edges, d_out);
 }
 
 extern "C" int rsseg_sobel_mag_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out)
 {
+    return rsseg_sobel_mag_rows_u8(ctx, d_q, H, W, 0, H, 3, d_out);
+}
+
+extern "C" int rsseg_laplacian_norm_rows_u8(rsseg_ctx *ctx, const uint8_t *d_q, int Hin, int W, int y0, int y1, int edges, float *d_out)
+{
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_q || !d_out || H < 1 || W < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "sobel_mag: bad arguments");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const dim3 g = grid2d(H, W);
-    const size_t nb = (size_t)g.x * g.y;
-    RSCHK(ws_reserve(ctx, nb * sizeof(float)));
-    RSCHK(pin_reserve(ctx, nb * sizeof(float)));
-    {
-        prof_scope ps(ctx, "stencil");
-        hipLaunchKernelGGL(k8_sobel, g, dim3(256), 0, ctx->stream, d_q, H, W, d_out, (float *)ctx->d_ws);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_ws, nb * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    float mx = 0.f;
-    for (size_t i = 0; i < nb; i++) mx = std::max(mx, ((const float *)ctx->h_pin)[i]);
-    double mxd = mx;
-    RSCHK(comm_allreduce_host(ctx, &mxd, 1, RSSEG_F64, RSSEG_MAX));
-    volatile float den = (float)mxd + 1e-10f;  // sobel_mag.max() + 1e-10 in float32
-    {
-        prof_scope ps(ctx, "stencil");
-        hipLaunchKernelGGL(k8_div, dim3((unsigned)std::min<int64_t>(2048, ceil_div64((int64_t)H * W, 256))), dim3(256), 0, ctx->stream,
-                           d_out, (int64_t)H * W, (float)den);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    return stream_sync(ctx);
+    return filter_rows<1>(ctx, "laplacian", d_q, Hin, W, y0, y1, edges, d_out);
+}
+
+extern "C" int rsseg_laplacian_norm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, float *d_out)
+{
+    return rsseg_laplacian_norm_rows_u8(ctx, d_q, H, W, 0, H, 3, d_out);
 }
 
 static int resize_rows(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw, int src_row0, int sh, float *d_dst, int dh_local,

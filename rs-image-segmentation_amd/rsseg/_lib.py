@@ -62,6 +62,9 @@ SIGNATURES = {
     "rsseg_pca_fit_transform_raw_f32": (_int, [_vp, _PP, _int, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double),
                                                _int, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                                C.POINTER(C.c_float)]),
+    "rsseg_pca_fit_transform_ext_f32": (_int, [_vp, _PP, _int, _i64, _i64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                               _int, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float)]),
     "rsseg_normalize_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, C.c_float, _vp]),
     "rsseg_glcm_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _PP]),
     "rsseg_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, _vp]),
@@ -69,6 +72,11 @@ SIGNATURES = {
     "rsseg_resize_bilinear_f32": (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
     "rsseg_resize_bilinear_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _int, _int, _int]),
     "rsseg_box_mean_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "rsseg_box_mean_rows_f32": (_int, [_vp, _PP, _int, _int, _int, _int, _int, _int, _int, _int, _int, _PP]),
+    "rsseg_local_std_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "rsseg_morph_rows_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "rsseg_laplacian_norm_rows_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "rsseg_sobel_mag_rows_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "rsseg_local_std_f32": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "rsseg_morph_gradient_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "rsseg_morph_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),

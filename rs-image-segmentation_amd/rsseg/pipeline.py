@@ -142,7 +142,7 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
     fused = all(q["center"] is not None for q in qb)
     pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
     level1 = [idx["ndwi"], idx["mndwi"], idx["ndvi"], idx["evi"], idx["ndbi"], idx["bsi"], pcs[0]]
-    ctx_planes = [ctx.box_mean(p, H, W, 7, L.BORDER_REFLECT) for p in level1]
+    ctx_planes = ctx.box_mean_multi(level1, H, W, 7, L.BORDER_REFLECT)   # the 7 channels of add_spatial_context in one launch
     if fused:
         nir2 = ctx.normalize(norm_all[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]))
     else:
@@ -316,3 +316,89 @@ def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: 
     planes = [idx[n] for n in INDEX_NAMES] + glcm + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes
+
+
+# ------------------------------------------------------------------------------------------------
+# the 19-feature stack of ONE raster sharded by rows (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------
+CONTEXT_HALO = 3   # 7x7 context mean of the level-1 planes (indices.py:770)
+TEXTURE_HALO = 2   # 5x5 blur / morphology (indices.py:433, 537-541); the 3x3 Sobel needs 1
+
+
+def stack19_halo_rows(H: int, r0: int, r1: int, glcm_window: int = 21, glcm_step: int = 21) -> Tuple[int, int]:
+    """Rows [e0, e1) of every band that the rank owning rows [r0, r1) of an H-row raster must hold for stack19_striped:
+    its stripe, 3 rows either side for the 7x7 context mean (hence 3 halo rows of the index planes and of PC0's inputs),
+    2 for the 5x5 blur / morphology, 1 for Sobel, and the rows of the texture windows its bilinear taps reach
+    (glcm_halo_rows) — clipped to the raster, where the operators' own border rules apply."""
+    _, _, i0, i1 = glcm_halo_rows(H, r0, r1, glcm_window, glcm_step)
+    return max(0, min(r0 - CONTEXT_HALO, i0)), min(H, max(r1 + CONTEXT_HALO, i1))
+
+
+def _rows_view(t, W: int, a: int, b: int):
+    """Rows [a, b) of a planar tensor as a 16-byte aligned device buffer: a view when the offset allows, else a copy."""
+    v = t[a * W:b * W]
+    return v if v.data_ptr() % 16 == 0 else v.clone()
+
+
+def stack19_striped(ctx: Context, bands_ext: Sequence, H: int, W: int, r0: int, r1: int, e0: int, glcm_window=21, glcm_step=21,
+                    glcm_levels=32):
+    """feature_stack19 for the rank that owns rows [r0, r1) of ONE H x W raster.  `bands_ext`: rows [e0, e1) of every
+    band, covering stack19_halo_rows(H, r0, r1, ...).  Order statistics, the PCA fit and the Sobel maximum reduce over
+    the OWNED rows of all ranks through the context's all-reduce hook; window operators run on stripe + halo with true
+    image borders only at the raster's edges.  Returns the 19 planes restricted to rows [r0, r1): bit for bit the rows
+    of the single-GPU feature_stack19 (tests/test_gpu_dist.py)."""
+    n_global = H * W
+    e1 = e0 + bands_ext[0].numel() // W
+    need0, need1 = stack19_halo_rows(H, r0, r1, glcm_window, glcm_step)
+    if need0 < e0 or need1 > e1 or not (0 <= r0 <= r1 <= H):
+        raise ValueError(f"bands_ext rows [{e0},{e1}) do not cover the rows [{need0},{need1}) that stripe [{r0},{r1}) needs")
+    own = [_rows_view(b, W, r0 - e0, r1 - e0) for b in bands_ext]
+    qb = band_quantile_bundles(ctx, own, n_global)
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+    fused = all(q["center"] is not None for q in qb)
+    # level 1 on rows [c0, c1): the stripe and the rows its 7x7 context mean reads
+    c0, c1 = max(r0 - CONTEXT_HALO, 0), min(r1 + CONTEXT_HALO, H)
+    bc = [_rows_view(b, W, c0 - e0, c1 - e0) for b in bands_ext]
+    fit = ((r0 - c0) * W, (r1 - r0) * W)
+    if fused:
+        idx, _ = spectral_indices(ctx, bc, lohi)
+        stats = [(q["center"], q["scale"]) for q in qb]
+        center = np.array([s[0] for s in stats], np.float32)
+        scale = np.array([s[1] for s in stats], np.float64)
+        pcs, comp, ratio, mean, ev = ctx.pca_fit_transform(bc, center, scale, len(bc), lohi, fit=fit)
+        lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
+    else:  # a band with NaNs: RobustScaler statistics by separate selects on the normalised stripes
+        idx, norms = spectral_indices(ctx, bc, lohi, want_norm=(True,) * 5)
+        norm_c = list(norms) + [ctx.normalize(bc[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bc))]
+        own_n = [_rows_view(p, W, r0 - c0, r1 - c0) for p in norm_c]
+        stats = [robust_scaler_stats(ctx, p, n_global) for p in own_n]
+        center = np.array([s[0] for s in stats], np.float32)
+        scale = np.array([s[1] for s in stats], np.float64)
+        pcs, comp, ratio, mean, ev = ctx.pca_fit_transform(norm_c, center, scale, len(bc), None, fit=fit)
+        lo2, hi2 = band_percentiles(ctx, own_n[3], (2, 98), n_global)
+        del norm_c, norms, own_n
+    level1_c = [idx["ndwi"], idx["mndwi"], idx["ndvi"], idx["evi"], idx["ndbi"], idx["bsi"], pcs[0]]
+    edges_c = (1 if c0 == 0 else 0) | (2 if c1 == H else 0)
+    ctx_planes = ctx.box_mean_multi(level1_c, c1 - c0, W, 7, L.BORDER_REFLECT, rows=(r0 - c0, r1 - c0), edges=edges_c)
+    level1 = [_rows_view(p, W, r0 - c0, r1 - c0) for p in level1_c]
+    # texture chain of the NIR band on rows [t0, t1): GLCM windows + the 5x5 / 3x3 operators' halos
+    j0, j1, i0, i1 = glcm_halo_rows(H, r0, r1, glcm_window, glcm_step)
+    m0, m1 = max(r0 - TEXTURE_HALO, 0), min(r1 + TEXTURE_HALO, H)
+    t0, t1 = min(i0, m0), max(i1, m1)
+    nir2 = ctx.normalize(_rows_view(bands_ext[3], W, t0 - e0, t1 - e0), float(lohi[3, 0]), float(lohi[3, 1]))
+    nir2 = ctx.normalize(nir2, float(lo2), float(hi2), out=nir2)
+    q = ctx.quantize_u8(_rows_view(nir2, W, i0 - t0, i1 - t0), float(glcm_levels - 1))
+    small, (oh, ow) = ctx.glcm(q, i1 - i0, W, glcm_levels, glcm_window, glcm_step)
+    sh = (H - glcm_window) // glcm_step + 1
+    glcm = dict(zip(GLCM_NAMES, [ctx.resize_bilinear_rows(m, oh, ow, j0, sh, r1 - r0, W, r0, H) for m in small]))
+    nir_m = _rows_view(nir2, W, m0 - t0, m1 - t0)
+    edges_m = (1 if m0 == 0 else 0) | (2 if m1 == H else 0)
+    rows_m = (r0 - m0, r1 - m0)
+    q255 = ctx.quantize_u8(nir_m, 255.0)
+    grad = ctx.morph_gradient(q255, m1 - m0, W, 5, rows=rows_m, edges=edges_m)
+    std5 = ctx.local_std(nir_m, m1 - m0, W, 5, rows=rows_m, edges=edges_m)
+    sob = ctx.sobel_mag(q255, m1 - m0, W, rows=rows_m, edges=edges_m)
+    planes = level1 + ctx_planes + [glcm["contrast"], glcm["homogeneity"], grad, std5, sob]
+    extras = dict(indices=idx, pca=pcs, pca_ratio=ratio, pca_model=dict(components=comp, mean=mean, explained_variance=ev, center=center, scale=scale),
+                  glcm=glcm, lohi=lohi, rows_level1=(c0, c1))
+    return planes, extras

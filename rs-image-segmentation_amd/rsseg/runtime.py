@@ -24,22 +24,37 @@ def _torch():
     return torch
 
 
-def make_allreduce_hook(buf, group=None):
+def make_allreduce_hook(buf, group=None, stream=None):
     """The Python side of rsseg_allreduce_fn: reduces `count` elements of `dtype` at byte `offset` of the
     communication buffer `buf` (a uint8 tensor; on the GPU in production, so the collective is RCCL over
-    xGMI; a CPU tensor with the gloo backend in the CPU tests) in place across the ranks of `group`."""
+    xGMI; a CPU tensor with the gloo backend in the CPU tests) in place across the ranks of `group`.
+
+    Stream contract (include/rsseg.h): the collective is ordered after the work already enqueued on the context's
+    stream and its result is visible to work enqueued there afterwards.  torch.distributed gives exactly that for the
+    CURRENT stream (ProcessGroupNCCL makes its communication stream wait for the current stream, and a synchronous
+    collective makes the current stream wait for the communication stream — no host synchronisation), so the hook
+    runs the collective with the context's stream current and does not block the host: the library pays one
+    hipStreamSynchronize per collective, after its copy-back.  Backends other than RCCL (gloo rehearsals on a CUDA
+    buffer) are followed by a stream synchronisation, since their stream semantics are not relied on."""
     torch = _torch()
     import torch.distributed as dist
     views = {L.F32: torch.float32, L.F64: torch.float64, L.I64: torch.int64}
     ops = {L.SUM: dist.ReduceOp.SUM, L.MIN: dist.ReduceOp.MIN, L.MAX: dist.ReduceOp.MAX}
+    is_nccl = buf.is_cuda and dist.get_backend(group) == "nccl"
 
     def hook(_user, offset, count, dtype, op):
         try:
             esz = 4 if dtype == L.F32 else 8
             t = buf[offset:offset + count * esz].view(views[dtype])
-            dist.all_reduce(t, op=ops[op], group=group)
-            if buf.is_cuda:
-                torch.cuda.current_stream().synchronize()
+            if buf.is_cuda and stream is not None:
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(t, op=ops[op], group=group)
+                    if not is_nccl:
+                        stream.synchronize()
+            else:
+                dist.all_reduce(t, op=ops[op], group=group)
+                if buf.is_cuda and not is_nccl:
+                    torch.cuda.current_stream().synchronize()
             return 0
         except Exception as e:  # noqa: BLE001 — must not propagate through the C frame
             print(f"[rsseg] all-reduce hook failed: {e!r}", flush=True)
@@ -85,7 +100,7 @@ class Context:
         import torch.distributed as dist
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self._comm_buf = torch.zeros(1 << 22, dtype=torch.uint8, device=self.device)
-        self._hook = L.ALLREDUCE_FN(make_allreduce_hook(self._comm_buf, group))
+        self._hook = L.ALLREDUCE_FN(make_allreduce_hook(self._comm_buf, group, self.torch_stream))
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
 
@@ -248,8 +263,9 @@ class Context:
 
     # ---- K3 ------------------------------------------------------------------------------------
     def pca_fit_transform(self, bands: Sequence, center: Optional[np.ndarray], scale: Optional[np.ndarray],
-                          n_components: int, lohi: Optional[np.ndarray] = None):
-        """lohi (nb x 2 float32, optional): the bands are RAW and are robust-normalised with these percentiles on the fly."""
+                          n_components: int, lohi: Optional[np.ndarray] = None, fit: Optional[Tuple[int, int]] = None):
+        """lohi (nb x 2 float32, optional): the bands are RAW and are robust-normalised with these percentiles on the fly.
+        fit=(offset, count) (optional): fit on that pixel range of the planes only, project all of them (stripe + halo rows)."""
         torch = _torch()
         nb, n = len(bands), bands[0].numel()
         outs = [self.empty(n, torch.float32) for _ in range(n_components)]
@@ -261,14 +277,21 @@ class Context:
         cptr = None if center is None else np.ascontiguousarray(center, np.float32).ctypes.data_as(fp)
         sc64 = None if scale is None else np.ascontiguousarray(scale, np.float64)
         sptr = None if sc64 is None else sc64.ctypes.data_as(C.POINTER(C.c_double))
-        if lohi is None:
+        lh = None
+        if lohi is not None:
+            lh = np.ascontiguousarray(lohi, np.float32).reshape(-1)
+            if lh.size != 2 * nb:
+                raise ValueError("pca_fit_transform: lohi must hold (lo, hi) for every band")
+        if fit is not None:
+            self._chk(self.lib.rsseg_pca_fit_transform_ext_f32(self.h, self._pp(bands), nb, n, int(fit[0]), int(fit[1]),
+                                                               None if lh is None else lh.ctypes.data_as(fp), cptr, sptr, n_components,
+                                                               self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
+                                                               mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        elif lohi is None:
             self._chk(self.lib.rsseg_pca_fit_transform_f32(self.h, self._pp(bands), nb, n, cptr, sptr, n_components,
                                                            self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
                                                            mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
         else:
-            lh = np.ascontiguousarray(lohi, np.float32).reshape(-1)
-            if lh.size != 2 * nb:
-                raise ValueError("pca_fit_transform: lohi must hold (lo, hi) for every band")
             self._chk(self.lib.rsseg_pca_fit_transform_raw_f32(self.h, self._pp(bands), nb, n, lh.ctypes.data_as(fp), cptr, sptr, n_components,
                                                                self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
                                                                mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
@@ -299,48 +322,61 @@ class Context:
         self._tag_minmax([dst])
         return dst
 
-    def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False):
+    # The window operators take `rows=(y0, y1)` and `edges` for row-sharded rasters: the plane holds H rows, rows
+    # [y0, y1) are produced (compact output); edges bit 0 / 1 = row 0 / row H - 1 is a true image edge (include/rsseg.h).
+    @staticmethod
+    def _rows(H, rows):
+        return (0, H) if rows is None else (int(rows[0]), int(rows[1]))
+
+    def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False, rows=None, edges: int = 3):
+        return self.box_mean_multi([plane], H, W, k, border, square, rows, edges)[0]
+
+    def box_mean_multi(self, planes: Sequence, H: int, W: int, k: int, border: int, square: bool = False, rows=None, edges: int = 3):
+        """k x k box mean of up to 8 planes of equal shape in one launch (add_spatial_context, indices.py:760-776)."""
         torch = _torch()
-        out = self.empty(H * W, torch.float32)
-        self._chk(self.lib.rsseg_box_mean_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, border, int(square),
-                                              C.c_void_p(out.data_ptr())))
+        y0, y1 = self._rows(H, rows)
+        outs = []
+        for g in range(0, len(planes), 8):
+            grp = list(planes[g:g + 8])
+            o = [self.empty((y1 - y0) * W, torch.float32) for _ in grp]
+            self._chk(self.lib.rsseg_box_mean_rows_f32(self.h, self._pp(grp), len(grp), H, W, y0, y1, edges, k, border, int(square), self._pp(o)))
+            outs += o
+        return outs
+
+    def local_std(self, plane, H: int, W: int, k: int, rows=None, edges: int = 3, variance: bool = False):
+        torch = _torch()
+        y0, y1 = self._rows(H, rows)
+        out = self.empty((y1 - y0) * W, torch.float32)
+        self._chk(self.lib.rsseg_local_std_rows_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, y0, y1, edges, k, int(variance),
+                                                    C.c_void_p(out.data_ptr())))
         return out
 
-    def local_std(self, plane, H: int, W: int, k: int):
-        torch = _torch()
-        out = self.empty(H * W, torch.float32)
-        self._chk(self.lib.rsseg_local_std_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
-        return out
+    def local_var(self, plane, H: int, W: int, k: int, rows=None, edges: int = 3):
+        return self.local_std(plane, H, W, k, rows, edges, variance=True)
 
-    def morph_gradient(self, q, H: int, W: int, k: int):
-        torch = _torch()
-        out = self.empty(H * W, torch.uint8)
-        self._chk(self.lib.rsseg_morph_gradient_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
-        return out
-
-    def morph(self, q, H: int, W: int, k: int, op: int):
+    def morph(self, q, H: int, W: int, k: int, op: int, rows=None, edges: int = 3):
         """op: L.MORPH_ERODE / DILATE / OPEN / CLOSE / GRADIENT on a uint8 plane; uint8 result."""
         torch = _torch()
-        out = self.empty(H * W, torch.uint8)
-        self._chk(self.lib.rsseg_morph_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, op, C.c_void_p(out.data_ptr())))
+        y0, y1 = self._rows(H, rows)
+        out = self.empty((y1 - y0) * W, torch.uint8)
+        self._chk(self.lib.rsseg_morph_rows_u8(self.h, C.c_void_p(q.data_ptr()), H, W, y0, y1, edges, k, op, C.c_void_p(out.data_ptr())))
         return out
 
-    def local_var(self, plane, H: int, W: int, k: int):
+    def morph_gradient(self, q, H: int, W: int, k: int, rows=None, edges: int = 3):
+        return self.morph(q, H, W, k, L.MORPH_GRADIENT, rows, edges)
+
+    def laplacian_norm(self, q, H: int, W: int, rows=None, edges: int = 3):
         torch = _torch()
-        out = self.empty(H * W, torch.float32)
-        self._chk(self.lib.rsseg_local_var_f32(self.h, C.c_void_p(plane.data_ptr()), H, W, k, C.c_void_p(out.data_ptr())))
+        y0, y1 = self._rows(H, rows)
+        out = self.empty((y1 - y0) * W, torch.float32)
+        self._chk(self.lib.rsseg_laplacian_norm_rows_u8(self.h, C.c_void_p(q.data_ptr()), H, W, y0, y1, edges, C.c_void_p(out.data_ptr())))
         return out
 
-    def laplacian_norm(self, q, H: int, W: int):
+    def sobel_mag(self, q, H: int, W: int, rows=None, edges: int = 3):
         torch = _torch()
-        out = self.empty(H * W, torch.float32)
-        self._chk(self.lib.rsseg_laplacian_norm_u8(self.h, C.c_void_p(q.data_ptr()), H, W, C.c_void_p(out.data_ptr())))
-        return out
-
-    def sobel_mag(self, q, H: int, W: int):
-        torch = _torch()
-        out = self.empty(H * W, torch.float32)
-        self._chk(self.lib.rsseg_sobel_mag_u8(self.h, C.c_void_p(q.data_ptr()), H, W, C.c_void_p(out.data_ptr())))
+        y0, y1 = self._rows(H, rows)
+        out = self.empty((y1 - y0) * W, torch.float32)
+        self._chk(self.lib.rsseg_sobel_mag_rows_u8(self.h, C.c_void_p(q.data_ptr()), H, W, y0, y1, edges, C.c_void_p(out.data_ptr())))
         return out
 
     # ---- K9/K10 --------------------------------------------------------------------------------

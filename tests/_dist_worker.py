@@ -79,6 +79,25 @@ def main():
         np.savez(os.path.join(outdir, f"out_{rank}.npz"), labels=labels.cpu().numpy(), n_iter=meta["n_iter"], r0=r0, r1=r1,
                  glcm0=planes[7].cpu().numpy(), glcm4=planes[11].cpu().numpy())
         ctx.close()
+    elif mode == "gpu_striped_c5":
+        # BASELINE config 5 on one raster sharded by rows: 19-feature stack with halos + forest labels
+        from rsseg import pipeline as P
+        from rsseg.runtime import Context
+        data = np.load(os.path.join(outdir, "input.npz"))
+        bands = data["bands"]
+        H, W = bands.shape[1:]
+        r0, r1 = P.stripe_rows(H, world, rank)
+        e0, e1 = P.stack19_halo_rows(H, r0, r1)
+        ctx = Context(0, use_dist=True)
+        ext = [ctx.to_device(bands[i, e0:e1].reshape(-1)) for i in range(bands.shape[0])]
+        planes, _ = P.stack19_striped(ctx, ext, H, W, r0, r1, e0)
+        forest = {k[7:]: data[k] for k in data.files if k.startswith("forest_")}
+        forest["n_features"] = int(forest["n_features"])
+        ctx.forest_load(forest)
+        labels = ctx.forest_predict(P.stack19_forest_planes(ctx, planes))
+        np.savez(os.path.join(outdir, f"out_{rank}.npz"), labels=labels.cpu().numpy(), r0=r0, r1=r1,
+                 **{f"p{i}": p.cpu().numpy() for i, p in enumerate(planes)})
+        ctx.close()
     dist.destroy_process_group()
 
 

@@ -101,3 +101,79 @@ def test_striped_config3_equals_single_gpu(ctx, oracle, tmp_path, world):
         assert int(o["n_iter"]) == meta["n_iter"]
         got.append(o["labels"])
     assert np.array_equal(np.concatenate(got), want)
+
+
+@pytest.mark.parametrize("H,W,world", [(190, 136, 2), (190, 136, 3), (173, 150, 3)])
+def test_striped_stack19_and_forest_equal_single_gpu(ctx, oracle, tmp_path, H, W, world):
+    """BASELINE config 5 sharded: every rank holds its stripe plus the halo rows of stack19_halo_rows (3 rows for the 7x7
+    context mean, 2 for the 5x5 operators, 1 for Sobel, the GLCM windows its bilinear taps reach).  The 19 planes and
+    the forest labels of every stripe equal the rows of the single-GPU result bit for bit (W = 150: rows that are not
+    16-byte aligned)."""
+    from sklearn.ensemble import RandomForestClassifier
+    from rsseg import pipeline as P
+    from rsseg.forest import flatten_forest
+    bands = oracle.synthetic_raster(H, W)
+    dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(7)]
+    planes, _ = P.feature_stack19(ctx, dev, H, W)
+    fp = P.stack19_forest_planes(ctx, planes)
+    X = np.stack([p.cpu().numpy() for p in fp], 1)
+    rng = np.random.default_rng(5)
+    sel = rng.choice(H * W, 3000, replace=False)
+    y = ((np.arange(H)[:, None] // 16 + np.arange(W)[None, :] // 16) % 5).reshape(-1)[sel]
+    model = RandomForestClassifier(n_estimators=12, max_depth=9, random_state=1).fit(X[sel], y)
+    forest = flatten_forest(model)
+    ctx.forest_load(forest)
+    want = ctx.forest_predict(fp).cpu().numpy()
+    assert np.array_equal(want, model.predict(X))
+    np.savez(tmp_path / "input.npz", bands=bands, **{f"forest_{k}": np.asarray(v) for k, v in forest.items()})
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "gpu_striped_c5", str(r), str(world), port, str(tmp_path)])
+             for r in range(world)]
+    _wait_all(procs)
+    host_planes = [p.cpu().numpy() for p in planes]
+    got = []
+    for r in range(world):
+        o = np.load(tmp_path / f"out_{r}.npz")
+        a, b = int(o["r0"]) * W, int(o["r1"]) * W
+        for i, hp in enumerate(host_planes):
+            assert np.array_equal(o[f"p{i}"], hp[a:b], equal_nan=True), (r, i)
+        got.append(o["labels"])
+    assert np.array_equal(np.concatenate(got), want)
+
+
+def test_window_ops_rows_form_equals_full_plane(ctx):
+    """Rows form of the window operators: any row range of a plane, computed from the range plus its halo rows only,
+    equals the same rows of the full-plane result; missing halo rows are refused."""
+    from rsseg import _lib as L
+    rng = np.random.default_rng(17)
+    H, W = 97, 300
+    x = rng.random((H, W)).astype(np.float32)
+    q = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    dx, dq = ctx.to_device(x.reshape(-1)), ctx.to_device(q.reshape(-1))
+    full = dict(box7=ctx.box_mean(dx, H, W, 7, L.BORDER_REFLECT), box5=ctx.box_mean(dx, H, W, 5, L.BORDER_REFLECT101, square=True),
+                std5=ctx.local_std(dx, H, W, 5), var7=ctx.local_var(dx, H, W, 7), grad5=ctx.morph_gradient(dq, H, W, 5),
+                open7=ctx.morph(dq, H, W, 7, L.MORPH_OPEN), close3=ctx.morph(dq, H, W, 3, L.MORPH_CLOSE), ero5=ctx.morph(dq, H, W, 5, L.MORPH_ERODE))
+    halo = dict(box7=3, box5=2, std5=2, var7=3, grad5=2, open7=6, close3=2, ero5=2)
+    for (a, b) in [(0, 40), (33, 64), (64, 97), (10, 11), (0, 97)]:
+        for name, R in halo.items():
+            s0, s1 = max(a - R, 0), min(b + R, H)
+            edges = (1 if s0 == 0 else 0) | (2 if s1 == H else 0)
+            src = (dq if name[0] in "goce" else dx)[s0 * W:s1 * W].clone()
+            rows = (a - s0, b - s0)
+            Hs = s1 - s0
+            got = {"box7": lambda: ctx.box_mean(src, Hs, W, 7, L.BORDER_REFLECT, rows=rows, edges=edges),
+                   "box5": lambda: ctx.box_mean(src, Hs, W, 5, L.BORDER_REFLECT101, square=True, rows=rows, edges=edges),
+                   "std5": lambda: ctx.local_std(src, Hs, W, 5, rows=rows, edges=edges),
+                   "var7": lambda: ctx.local_var(src, Hs, W, 7, rows=rows, edges=edges),
+                   "grad5": lambda: ctx.morph_gradient(src, Hs, W, 5, rows=rows, edges=edges),
+                   "open7": lambda: ctx.morph(src, Hs, W, 7, L.MORPH_OPEN, rows=rows, edges=edges),
+                   "close3": lambda: ctx.morph(src, Hs, W, 3, L.MORPH_CLOSE, rows=rows, edges=edges),
+                   "ero5": lambda: ctx.morph(src, Hs, W, 5, L.MORPH_ERODE, rows=rows, edges=edges)}[name]()
+            assert np.array_equal(got.cpu().numpy(), full[name].cpu().numpy()[a * W:b * W]), (name, a, b)
+    with pytest.raises(ValueError):   # an interior stripe without its halo rows
+        ctx.box_mean(dx[10 * W:20 * W].clone(), 10, W, 7, L.BORDER_REFLECT, rows=(0, 10), edges=0)
+    # the multi-plane launch equals the single-plane launches
+    ps = [ctx.to_device(rng.random(H * W).astype(np.float32)) for _ in range(7)]
+    multi = ctx.box_mean_multi(ps, H, W, 7, L.BORDER_REFLECT)
+    for p, m in zip(ps, multi):
+        assert np.array_equal(m.cpu().numpy(), ctx.box_mean(p, H, W, 7, L.BORDER_REFLECT).cpu().numpy())
