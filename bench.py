@@ -72,6 +72,7 @@ def family_table(cfg, F, glcm_step, k, n_pca):
         "lloyd": ("hbm", 4 * F + 2),
         "select": ("hbm", 4),                                              # one radix pass over one float32 plane
         "indices": ("hbm", 20 + idx_out),
+        "normalize": ("hbm", 8), "quantize": ("hbm", 5),
         "gram": ("hbm", 28), "project": ("hbm", 28 + 4 * n_pca),
         "resize": ("hbm", 8),                                              # 4 taps from cache, one plane out
         "box": ("hbm", 8), "ctxmean": ("hbm", 8 * 7), "morph": ("hbm", 2), "filt_max": ("hbm", 1), "filt_write": ("hbm", 5),
@@ -119,7 +120,7 @@ def glcm_issue_cycles():
 def cpu_baseline(tile_bands, H, W, crop, cfg, k, glcm_step, model=None):
     """the CPU counterpart harness (oracle/cpu_harness.py: NumPy glue restated + the scikit-learn
     estimators the reference calls + C restatements of the cv2 / skimage stages) on a crop of the same raster, once with
-    every host core and once with one thread.  The single-threaded C GLCM is timed once and used in both figures."""
+    every host core and once with one thread."""
     from oracle import cpu_harness as CH
     c = min(crop, H, W)
     b = [t.reshape(H, W)[:c, :c].cpu().numpy().copy() for t in tile_bands]
@@ -131,8 +132,7 @@ def cpu_baseline(tile_bands, H, W, crop, cfg, k, glcm_step, model=None):
         stages = {"all_cores": {s: round(v, 3) for s, v in allc.items()}, "one_thread": {s: round(v, 3) for s, v in one.items()}}
     else:
         allc = CH.config23(b, cfg, k, glcm_step, None)
-        gl = (allc["glcm"], allc.pop("_glcm_planes")) if cfg == "c3" else None
-        one = CH.config23(b, cfg, k, glcm_step, 1, gl)
+        one = CH.config23(b, cfg, k, glcm_step, 1)
         keys = [s for s in allc if s != "n_iter"]
         tot_all, tot_one = sum(allc[s] for s in keys), sum(one[s] for s in keys)
         stages = {"all_cores": {s: round(allc[s], 3) for s in keys}, "one_thread": {s: round(one[s], 3) for s in keys},
@@ -145,7 +145,6 @@ def cpu_baseline(tile_bands, H, W, crop, cfg, k, glcm_step, model=None):
             "sample": (f"{c}x{c}x7 crop of the same synthetic raster, full {cfg} path: NumPy glue restated + scikit-learn "
                        "RobustScaler/PCA/MinMaxScaler/KMeans" + ("/RandomForest.predict" if cfg == "c5" else "")
                        + " + C/NumPy restatements of the cv2/skimage stages"
-                       + ("; GLCM (single-threaded C, " f"{allc['glcm']:.1f} s) timed once and counted in both figures" if cfg == "c3" else "")
                        + f"; extrapolated linearly in pixels to the full raster; {tot_all:.1f} s all cores, {tot_one:.1f} s one thread")}
 
 
@@ -157,7 +156,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--size", type=int, default=0, help="raster edge (default 16384 for c3 / c5, 4096 for c2)")
     ap.add_argument("--glcm-step", type=int, default=1)
-    ap.add_argument("--cpu-crop", type=int, default=1536)
+    ap.add_argument("--cpu-crop", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and GLCM-step-7 side measurements")
     ap.add_argument("--weak", action="store_true", help="N > 1: H rows per rank ((N*H) x W scene) instead of one H x W raster split N ways")

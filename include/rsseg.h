@@ -82,7 +82,7 @@ int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn f
                        void *d_comm, size_t comm_bytes);
 
 /* Per-kernel timing (HIP events on the context's stream, around each launch of the named
- * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices",
+ * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices", "normalize", "quantize", "range",
  * "select", "kpp", "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
  * of Sobel / Laplacian), "project", "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
 int rsseg_prof_enable(rsseg_ctx *ctx, int on);

@@ -57,9 +57,9 @@ def _timed(fn):
     return out, time.perf_counter() - t0
 
 
-def config23(bands: List[np.ndarray], cfg: str, k: int, glcm_step: int, threads, glcm_seconds=None) -> Dict:
-    """BASELINE configs[1] / [2] on host arrays: per-stage wall seconds.  `threads`: None = every core, 1 = one thread.
-    The GLCM restatement (oracle.c) is single-threaded C; its seconds are measured once and passed on (`glcm_seconds`)."""
+def config23(bands: List[np.ndarray], cfg: str, k: int, glcm_step: int, threads) -> Dict:
+    """BASELINE configs[1] / [2] on host arrays: per-stage wall seconds.  `threads`: None = every core, 1 = one thread
+    (threadpoolctl limits OpenBLAS, scikit-learn's OpenMP and the OpenMP loop of the GLCM restatement in oracle.c)."""
     from threadpoolctl import threadpool_limits
     st: Dict[str, float] = {}
     with threadpool_limits(limits=threads):
@@ -69,11 +69,7 @@ def config23(bands: List[np.ndarray], cfg: str, k: int, glcm_step: int, threads,
                                                O.calculate_mndwi(g, s), O.calculate_ndbi(s, n), O.calculate_bsi(bl, r, n, s)])
         if cfg == "c3":
             (pcs, _, _), st["pca"] = _timed(lambda: perform_pca_sklearn(norm, 3))
-            if glcm_seconds is None:
-                (gl, _), st["glcm"] = _timed(lambda: O.calculate_glcm_features(norm[3], 32, 7, glcm_step))
-                st["_glcm_planes"] = gl
-            else:
-                gl, st["glcm"] = glcm_seconds[1], glcm_seconds[0]
+            (gl, _), st["glcm"] = _timed(lambda: O.calculate_glcm_features(norm[3], 32, 7, glcm_step))
             feats = feats + [gl[x] for x in GLCM_KEYS] + list(pcs)
         (labels, n_iter), st["kmeans"] = _timed(lambda: kmeans_sklearn(feats, k))
     st["n_iter"] = n_iter

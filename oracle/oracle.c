@@ -77,10 +77,21 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
     if (levels < 2 || levels > 256 || win < 2 || win > H || win > W || step < 1) return -1;
     const int oh = (H - win) / step + 1, ow = (W - win) / step + 1;
     const int LL = levels * levels;
+    int err = 0;
+    /* window rows are independent: OpenMP over them (the CPU baseline's "all cores" leg; one thread under
+     * threadpool_limits(1)).  Every thread owns its co-occurrence buffers; results do not depend on the thread count. */
+#pragma omp parallel
+    {
     uint32_t *G = (uint32_t *)malloc(sizeof(uint32_t) * LL);
     double *P = (double *)malloc(sizeof(double) * LL);
-    if (!G || !P) return -2;
+    if (!G || !P) {
+#pragma omp atomic write
+        err = -2;
+    }
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 4)
     for (int oi = 0; oi < oh; oi++) {
+        if (err) continue;
         for (int oj = 0; oj < ow; oj++) {
             const uint8_t *wp = q + (size_t)(oi * step) * W + (size_t)oj * step;
             double pc[4], pd[4], ph[4], pe[4], pr[4];
@@ -155,7 +166,11 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
                  * na = win*(win-1) for 0/90 degrees, nb = (win-1)^2 for 45/135 degrees.  The mean over
                  * the angles is taken over the common denominator 4*na*nb (one division per property). */
                 const int64_t na = aNp[0], nb = aNp[1];
-                if (aNp[2] != na || aNp[3] != nb || na == 0 || nb == 0) { free(G); free(P); return -3; }
+                if (aNp[2] != na || aNp[3] != nb || na == 0 || nb == 0) {
+#pragma omp atomic write
+                    err = -3;
+                    break;
+                }
                 const double dna = (double)na, dnb = (double)nb;
                 const double den4 = (double)(4 * na * nb), den8 = (double)(8 * na * nb);
                 contrast[o] = (float)((double)((aS2[0] + aS2[2]) * nb + (aS2[1] + aS2[3]) * na) / den4);
@@ -177,7 +192,8 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
         }
     }
     free(G); free(P);
-    return 0;
+    }
+    return err;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -75,6 +75,7 @@ extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
     if (ctx->forest.d_nodes) (void)hipFree(ctx->forest.d_nodes);
     if (ctx->forest.d_leafval) (void)hipFree(ctx->forest.d_leafval);
     if (ctx->forest.d_treeoff) (void)hipFree(ctx->forest.d_treeoff);
+    if (ctx->forest.d_groups) (void)hipFree(ctx->forest.d_groups);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

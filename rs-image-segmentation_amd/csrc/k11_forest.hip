@@ -6,17 +6,29 @@
 // RandomForestClassifier.predict: sklearn/ensemble/_forest.py:640 (float32 cast), 903-906, 948-962;
 // Tree._apply_dense sklearn/tree/_tree.pyx:955-996.
 //
-// Forest layout (built once by rsseg_forest_load): every tree is renumbered in BREADTH-FIRST order, so
-//   * the two children of a node are adjacent (left = c, right = c + 1): a node is 8 bytes
-//       { float thr ; uint32 : bits 0-23 left child (or leaf-value row), 24-29 feature, 30 missing->left, 31 leaf }
-//   * the first NTOP nodes of a tree are its upper levels: the workgroup copies that block into LDS
-//     (double-buffered, the copy of the next pair of trees overlaps the walk of the current pair) and only
-//     the levels below it are gathered from L2 / Infinity Cache.
-// `X[i,f] <= threshold` compares a float32 feature with a float64 threshold; that is equivalent to
-// comparing with the threshold rounded DOWN to float32, which is what thr holds.
-// The pixel's features are staged once in LDS ([F][1024] floats, bank = lane, conflict-free for any
-// per-lane feature choice).  A leaf whose value row is one-hot carries its class in the node (no gather).
-// Gather-latency-bound, not HBM-bound: algorithmic HBM traffic is 4F B/px in + 8 B/px out.
+// Forest layout (built once by rsseg_forest_load): every tree is renumbered in BREADTH-FIRST order, so the two children
+// of a node are adjacent (left = c, right = c + 1) and a node is 8 bytes:
+//   internal  { float thr ; uint32 : bits 0-23 left child, 24-29 feature, 30 missing->left }
+//   leaf      { NaN whose payload (bits 0-21) is the leaf's row in the vote table ; uint32 : bits 0-23 the leaf's OWN index,
+//               bit 30, bit 31 }
+// Vote table: rows of NC = 4 / 8 / 16 / 32 float64 (n_classes padded with zeros); rows 0 .. n_classes-1 are the one-hot
+// rows shared by every pure leaf, the mixed leaves follow.  Every leaf votes the same way — acc[c] += row[c], 16-byte
+// loads, no branch; pure leaves of a wave hit the same few cache lines.
+// `X[i,f] <= threshold` compares a float32 feature with a float64 threshold; that is equivalent to comparing with the
+// threshold rounded DOWN to float32, which is what thr holds.  A walk step is next = left + (x > thr): on a leaf
+// x > NaN is false for every x, so the step returns the leaf itself — leaves are fixed points and the inner loop needs
+// no leaf test per chain, no select and no branch.
+// The pixel's features are staged once in LDS ([F][1024] floats, bank = lane, conflict-free for any per-lane feature).
+//
+// Two kernels:
+//   k11_forest_lds   trees are taken in groups of <= 4 consecutive trees whose nodes (contiguous in the node array) fit
+//                    the LDS beside the features; the whole group is copied with 16-byte loads (prefetched into
+//                    registers during the walk of the previous group) and every step is two ds_reads.  Measured
+//                    (profiles/r02_forest_pmc.md): the walk is VALU-issue-bound — LDS array 13 % busy, bank conflicts
+//                    2 % (neighbouring pixels share paths) — so the loop is written for instruction count: 9 VALU per
+//                    tree step.
+//   k11_forest_gen   any forest: the first ntop nodes of each of 4 trees in LDS, deeper nodes by global loads.
+// Algorithmic HBM traffic is 4F B/px in + 8 B/px out; the kernel's bound is VALU issue, reported as node visits / s.
 #include <algorithm>
 #include <cmath>
 #include <queue>
@@ -29,10 +41,12 @@ struct __align__(8) rf_node {
 };
 #define RF_LEAF 0x80000000u
 #define RF_MISS 0x40000000u
-#define RF_PURE 0x20000000u  // leaf only: value row is one-hot, class in bits 24-28
+#define RF_NAN_BITS 0x7fc00000u   // leaf thr: quiet NaN | payload
+#define RF_PAY_MASK 0x003fffffu   // payload: row of the vote table
 
-#define RF_THREADS_MAX 1024
-#define RF_NCMAX 8
+#define RF_NCMAX 32
+#define RF_C 4        // trees walked at a time (independent chains of dependent LDS reads)
+#define RF_TH 1024    // pixels per workgroup
 
 struct rf_planes {
     const float *p[RSSEG_MAX_FEATURES];
@@ -45,123 +59,40 @@ struct rf_tree {
     int pad;
 };
 
-// One step of a walk: from node `nd` of a tree whose first `lim` nodes are in LDS (`buf`), the rest in `tn`.
-// The next node is fetched through ONE generic pointer (flat load: the aperture check per lane replaces a divergent
-// LDS / global branch pair).  NANS = false: the workgroup's pixels hold no NaN, so the missing-value rule is skipped.
-template <int RF_THREADS, bool NANS>
-__device__ __forceinline__ rf_node rf_step(const rf_node nd, const float *__restrict__ feat, const rf_node *buf, int lim, const rf_node *tn)
+struct rf_group {   // k11_forest_lds: trees [first, first + count) whose nodes [node_base, node_base + n_nodes) share the LDS
+    int first, count;
+    int node_base;  // even (16-byte aligned copy); <= node_off of the first tree
+    int n_nodes;    // nodes copied (from node_base)
+};
+
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const rf_node lds_cnode;
+
+// The vote of a leaf: its row of the table, added in tree order (x + 0.0 == x, so a one-hot row adds a single 1.0).
+template <int NC>
+__device__ __forceinline__ void rf_row_load(const rf_node nd, const double *__restrict__ leafval, double (&row)[NC])
 {
-    const float x = feat[((nd.bits >> 24) & 63u) * RF_THREADS + threadIdx.x];
-    const unsigned left = nd.bits & 0xffffffu;
-    bool go_left = x <= nd.thr;
-    if (NANS) go_left = go_left || ((nd.bits & RF_MISS) != 0 && x != x);
-    const unsigned next = left + (go_left ? 0u : 1u);
-    const rf_node *p = (int)next < lim ? buf + next : tn + next;
-    return *p;
+    const double2 *v = reinterpret_cast<const double2 *>(leafval + (size_t)(__float_as_uint(nd.thr) & RF_PAY_MASK) * NC);
+#pragma unroll
+    for (int c = 0; c < NC / 2; c++) {
+        const double2 t = v[c];
+        row[2 * c] = t.x;
+        row[2 * c + 1] = t.y;
+    }
+}
+template <int NC>
+__device__ __forceinline__ void rf_vote(const rf_node nd, const double *__restrict__ leafval, double (&acc)[NC])
+{
+    double row[NC];
+    rf_row_load<NC>(nd, leafval, row);
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] += row[c];
 }
 
 template <int NC>
-__device__ __forceinline__ void rf_vote(const rf_node nd, const rf_tree &tr, const double *__restrict__ leafval, int n_classes, double (&acc)[NC])
+__device__ __forceinline__ void rf_finish(const double (&acc)[NC], int n_trees, int n_classes, const long long *__restrict__ classes,
+                                          long long *__restrict__ out, int64_t i)
 {
-    if (nd.bits & RF_PURE) {
-        const int cls = (nd.bits >> 24) & 31u;
-#pragma unroll
-        for (int c = 0; c < NC; c++) acc[c] += (c == cls) ? 1.0 : 0.0;
-    } else {
-        const double *v = leafval + (size_t)(tr.leaf_off + (int)(nd.bits & 0xffffffu)) * n_classes;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (c < n_classes) acc[c] += v[c];
-    }
-}
-
-// Trees are walked TWO AT A TIME per pixel (independent dependency chains: the walk is a chain of dependent
-// LDS / L2 gathers, so a second chain nearly doubles what a wave keeps in flight); votes are still added in
-// tree order.  LDS: features + 2 x 2 top blocks (the pair being walked, the pair being copied in).
-template <int NC, int RF_THREADS>
-__global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
-                                                         const rf_tree *__restrict__ trees, int n_trees, int ntop,
-                                                         const double *__restrict__ leafval, int n_classes,
-                                                         const long long *__restrict__ classes, long long *__restrict__ out)
-{
-    extern __shared__ __align__(16) char smem[];
-    float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_THREADS]
-    rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_THREADS);       // [2 pairs][2 trees][ntop]
-    const int64_t i = (int64_t)blockIdx.x * RF_THREADS + threadIdx.x;
-    int my_nan = 0;
-    for (int f = 0; f < F; f++) {
-        const float v = i < n ? pl.p[f][i] : 0.f;
-        my_nan |= v != v;
-        feat[f * RF_THREADS + threadIdx.x] = v;
-    }
-    const bool any_nan = __syncthreads_or(my_nan) != 0;  // workgroup-uniform
-    constexpr int NPRE = 8192 / RF_THREADS;  // 2 * ntop <= 8192 nodes per pair
-    // pair 0's top blocks
-    for (int h = 0; h < 2 && h < n_trees; h++) {
-        const rf_tree t0 = trees[h];
-        const int cnt = t0.n_nodes < ntop ? t0.n_nodes : ntop;
-        for (int j = threadIdx.x; j < cnt; j += RF_THREADS) top[(size_t)h * ntop + j] = nodes[t0.node_off + j];
-    }
-    __syncthreads();
-    double acc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) acc[c] = 0.0;
-    const int n_pairs = (n_trees + 1) / 2;
-    for (int pr = 0; pr < n_pairs; pr++) {
-        const int t = 2 * pr;
-        const bool two = t + 1 < n_trees;
-        const rf_tree trA = trees[t], trB = trees[two ? t + 1 : t];
-        const rf_node *bufA = top + (size_t)((pr & 1) * 2) * ntop, *bufB = bufA + ntop;
-        // issue the copy of the next pair's top blocks (held in registers during the walk)
-        rf_node pre[NPRE];
-        int cntA = 0, cntB = 0, offA = 0, offB = 0;
-        if (t + 2 < n_trees) {
-            const rf_tree tn = trees[t + 2];
-            cntA = tn.n_nodes < ntop ? tn.n_nodes : ntop;
-            offA = tn.node_off;
-            if (t + 3 < n_trees) {
-                const rf_tree tm = trees[t + 3];
-                cntB = tm.n_nodes < ntop ? tm.n_nodes : ntop;
-                offB = tm.node_off;
-            }
-#pragma unroll
-            for (int r = 0; r < NPRE; r++) {
-                const int j = threadIdx.x + r * RF_THREADS;  // [0, 2*ntop): first the A block, then the B block
-                if (j < ntop) { if (j < cntA) pre[r] = nodes[offA + j]; }
-                else if (j - ntop < cntB) pre[r] = nodes[offB + (j - ntop)];
-            }
-        }
-        if (i < n) {
-            const rf_node *tnA = nodes + trA.node_off, *tnB = nodes + trB.node_off;
-            const int limA = trA.n_nodes < ntop ? trA.n_nodes : ntop, limB = trB.n_nodes < ntop ? trB.n_nodes : ntop;
-            rf_node a = bufA[0], b = two ? bufB[0] : a;
-            if (!two) b.bits = RF_LEAF;
-            if (any_nan) {
-                while (!((a.bits & b.bits) & RF_LEAF)) {
-                    if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS, true>(a, feat, bufA, limA, tnA);
-                    if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS, true>(b, feat, bufB, limB, tnB);
-                }
-            } else {
-                while (!((a.bits & b.bits) & RF_LEAF)) {
-                    if (!(a.bits & RF_LEAF)) a = rf_step<RF_THREADS, false>(a, feat, bufA, limA, tnA);
-                    if (!(b.bits & RF_LEAF)) b = rf_step<RF_THREADS, false>(b, feat, bufB, limB, tnB);
-                }
-            }
-            rf_vote<NC>(a, trA, leafval, n_classes, acc);
-            if (two) rf_vote<NC>(b, trB, leafval, n_classes, acc);
-        }
-        if (t + 2 < n_trees) {
-            rf_node *nb = top + (size_t)(((pr + 1) & 1) * 2) * ntop;
-#pragma unroll
-            for (int r = 0; r < NPRE; r++) {
-                const int j = threadIdx.x + r * RF_THREADS;
-                if (j < ntop) { if (j < cntA) nb[j] = pre[r]; }
-                else if (j - ntop < cntB) nb[j] = pre[r];
-            }
-        }
-        __syncthreads();
-    }
-    if (i >= n) return;
     int best = 0;
     double bv = acc[0] / (double)n_trees;
 #pragma unroll
@@ -171,6 +102,299 @@ __global__ __launch_bounds__(RF_THREADS) void k11_forest(rf_planes pl, int F, in
             if (p > bv) { bv = p; best = c; }
         }
     out[i] = classes[best];
+}
+
+__device__ __forceinline__ int rf_stage_features(const rf_planes &pl, int F, int64_t n, int64_t i, float *feat)
+{
+    int my_nan = 0;
+    for (int f = 0; f < F; f++) {
+        const float v = i < n ? pl.p[f][i] : 0.f;
+        my_nan |= v != v;
+        feat[f * RF_TH + threadIdx.x] = v;
+    }
+    return my_nan;
+}
+
+// ---- k11_forest_lds ------------------------------------------------------------------------------------------------
+// A thread owns RF_PX pixels of its workgroup's 1024 and walks RF_C trees for each: RF_PX * RF_C independent chains.
+// One round advances every chain by one node: all feature reads back to back, all node reads back to back, no control
+// flow (leaves are fixed points).  Lanes leave the loop when all their chains sit on leaves.
+#define RF_PX 1                      // pixels per thread (k11_forest_lds): 512 threads per workgroup
+#define RF_LT (RF_TH / RF_PX)
+#define RF_NCH (RF_PX * RF_C)
+
+template <bool NANS>
+__device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C])
+{
+    for (;;) {
+        unsigned all = nd[0].bits;
+#pragma unroll
+        for (int q = 1; q < RF_NCH; q++) all &= nd[q].bits;
+        if (all & RF_LEAF) break;
+        float x[RF_NCH];
+#pragma unroll
+        for (int q = 0; q < RF_NCH; q++)   // chain q: pixel q / RF_C of the thread, tree q % RF_C of the group
+            x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * (RF_LT * 4) + ((nd[q].bits >> 24) & 63u) * (RF_TH * 4));
+#pragma unroll
+        for (int q = 0; q < RF_NCH; q++) {
+            bool go_right = x[q] > nd[q].thr;
+            if (NANS) go_right = go_right || (x[q] != x[q] && !(nd[q].bits & RF_MISS));
+            const unsigned next = (nd[q].bits & 0xffffffu) + (go_right ? 1u : 0u);
+            lds_cnode *p = (lds_cnode *)(base[q % RF_C] + next * 8u);
+            nd[q].thr = p->thr;
+            nd[q].bits = p->bits;
+        }
+    }
+}
+
+#define RF_NPRE (6 * RF_PX)   // 16-byte pieces (2 nodes) a thread prefetches per group: cap <= 12 * 1024 nodes
+
+template <int NC>
+__global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
+                                                        const rf_tree *__restrict__ trees, const rf_group *__restrict__ groups, int n_groups,
+                                                        int cap2 /* node area in 16-byte pieces */, int n_trees, const double *__restrict__ leafval,
+                                                        int n_classes, const long long *__restrict__ classes, long long *__restrict__ out)
+{
+    extern __shared__ __align__(16) char smem[];
+    float *feat = reinterpret_cast<float *>(smem);                             // [F][RF_TH]
+    uint4 *top = reinterpret_cast<uint4 *>(feat + (size_t)F * RF_TH);          // the current group's nodes, two per uint4
+    const int64_t i0 = (int64_t)blockIdx.x * RF_TH + threadIdx.x;             // pixel p of the thread: i0 + p * RF_LT
+    int my_nan = 0;
+    for (int f = 0; f < F; f++)
+#pragma unroll
+        for (int p = 0; p < RF_PX; p++) {
+            const int64_t i = i0 + p * RF_LT;
+            const float v = i < n ? pl.p[f][i] : 0.f;
+            my_nan |= v != v;
+            feat[f * RF_TH + p * RF_LT + threadIdx.x] = v;
+        }
+    {
+        const rf_group g0 = groups[0];
+        const uint4 *src = reinterpret_cast<const uint4 *>(nodes + g0.node_base);
+        for (int j = threadIdx.x; j < (g0.n_nodes + 1) / 2; j += RF_LT) top[j] = src[j];
+        // a fixed-point leaf behind the node area for the unused chains of a group with fewer than RF_C trees
+        if (threadIdx.x == 0) top[cap2] = make_uint4(RF_NAN_BITS, RF_LEAF | RF_MISS, RF_NAN_BITS, RF_LEAF | RF_MISS);
+    }
+    const bool any_nan = __syncthreads_or(my_nan) != 0;  // workgroup-uniform; also the barrier behind the fills above
+    const unsigned feat_tid = (unsigned)(uintptr_t)(lds_cfloat *)feat + threadIdx.x * 4u;
+    const unsigned top_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)top;
+    double acc[RF_PX][NC];
+#pragma unroll
+    for (int p = 0; p < RF_PX; p++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[p][c] = 0.0;
+    for (int g = 0; g < n_groups; g++) {
+        const rf_group gr = groups[g];
+        // the next group's nodes: one contiguous range, 16-byte loads, held in registers during the walk
+        uint4 pre[RF_NPRE];
+        const bool more = g + 1 < n_groups;
+        int npiece = 0;
+        if (more) {
+            const rf_group gn = groups[g + 1];
+            npiece = (gn.n_nodes + 1) / 2;
+            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + gn.node_base);
+#pragma unroll
+            for (int r = 0; r < RF_NPRE; r++) {
+                const int j = threadIdx.x + r * RF_LT;
+                if (j < npiece) pre[r] = src[j];
+            }
+        }
+        rf_node nd[RF_NCH];
+        unsigned base[RF_C];
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) {
+            const rf_tree tr = trees[c < gr.count ? gr.first + c : gr.first];
+            base[c] = c < gr.count ? top_addr + (unsigned)(tr.node_off - gr.node_base) * 8u : top_addr + (unsigned)cap2 * 16u;
+            lds_cnode *p = (lds_cnode *)base[c];
+#pragma unroll
+            for (int px = 0; px < RF_PX; px++) {   // lanes without a pixel walk their zero features (no special case in the loop)
+                nd[px * RF_C + c].thr = p->thr;
+                nd[px * RF_C + c].bits = p->bits;
+            }
+        }
+        if (any_nan) rf_walk_lds<true>(nd, feat_tid, base);
+        else rf_walk_lds<false>(nd, feat_tid, base);
+        // votes: the rows of all chains are requested now and added (in tree order) after the refill below, whose two
+        // barriers hide the latency of the gathers; NC > 8 would need too many registers and votes chain by chain
+        constexpr bool PIPE = NC <= 8;
+        double rows[PIPE ? RF_NCH : 1][NC];
+        if (PIPE) {
+#pragma unroll
+            for (int q = 0; q < RF_NCH; q++) rf_row_load<NC>(nd[q], leafval, rows[PIPE ? q : 0]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < RF_NCH; q++)
+                if (q % RF_C < gr.count && i0 + (q / RF_C) * RF_LT < n) rf_vote<NC>(nd[q], leafval, acc[q / RF_C]);
+        }
+        if (more) {
+            __syncthreads();  // every wave is done with the current group
+#pragma unroll
+            for (int r = 0; r < RF_NPRE; r++) {
+                const int j = threadIdx.x + r * RF_LT;
+                if (j < npiece) top[j] = pre[r];
+            }
+            __syncthreads();
+        }
+        if (PIPE) {
+#pragma unroll
+            for (int q = 0; q < RF_NCH; q++)
+                if (q % RF_C < gr.count) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) acc[q / RF_C][c] += rows[PIPE ? q : 0][c];
+                }
+        }
+    }
+#pragma unroll
+    for (int px = 0; px < RF_PX; px++)
+        if (i0 + px * RF_LT < n) rf_finish<NC>(acc[px], n_trees, n_classes, classes, out, i0 + px * RF_LT);
+}
+
+// ---- k11_forest_gen ------------------------------------------------------------------------------------------------
+// Every load of a round is issued unconditionally (a chain on its leaf reads node 0 of its block and keeps its leaf by a
+// select): a load inside a per-chain `if` makes the compiler wait for each LDS read before it issues the next one,
+// which serialises the chains.  Only a step to a node beyond the LDS block takes a predicated global load.
+template <bool NANS>
+__device__ __forceinline__ void rf_walk_gen(rf_node (&nd)[RF_C], lds_cfloat *feat, lds_cnode *top, int ntop, const int (&lim)[RF_C],
+                                            const rf_node *__restrict__ nodes, const int (&noff)[RF_C])
+{
+    for (;;) {
+        unsigned all = 0xffffffffu;
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) all &= nd[c].bits;
+        if (all & RF_LEAF) break;   // every chain of this lane sits on a leaf (lanes leave the loop one by one)
+        float x[RF_C];
+        unsigned leafm[RF_C];  // all ones when the chain sits on its leaf (bit 31 of the node), as a mask: no control flow
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) {
+            leafm[c] = (unsigned)((int)nd[c].bits >> 31);
+            const unsigned f = (nd[c].bits >> 24) & 63u & ~leafm[c];
+            x[c] = feat[f * RF_TH + threadIdx.x];
+        }
+        unsigned next[RF_C], out[RF_C];
+        rf_node ld[RF_C];
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) {
+            bool go_right = x[c] > nd[c].thr;
+            if (NANS) go_right = go_right || (x[c] != x[c] && !(nd[c].bits & RF_MISS));
+            next[c] = (nd[c].bits & 0xffffffu) + (go_right ? 1u : 0u);
+            out[c] = ((int)next[c] >= lim[c] ? 0xffffffffu : 0u) & ~leafm[c];
+            const unsigned a = next[c] & ~(leafm[c] | out[c]);
+            lds_cnode *p = top + c * ntop + a;
+            ld[c].thr = p->thr;
+            ld[c].bits = p->bits;
+        }
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) {
+            nd[c].thr = leafm[c] ? nd[c].thr : ld[c].thr;
+            nd[c].bits = leafm[c] ? nd[c].bits : ld[c].bits;
+        }
+        if (out[0] | out[1] | out[2] | out[3]) {
+#pragma unroll
+            for (int c = 0; c < RF_C; c++)
+                if (out[c]) nd[c] = nodes[noff[c] + next[c]];
+        }
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
+                                                        const rf_tree *__restrict__ trees, int n_trees, int ntop,
+                                                        const double *__restrict__ leafval, int n_classes,
+                                                        const long long *__restrict__ classes, long long *__restrict__ out)
+{
+    extern __shared__ __align__(16) char smem[];
+    float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_TH]
+    rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_TH);            // [RF_C][ntop]
+    const int64_t i = (int64_t)blockIdx.x * RF_TH + threadIdx.x;
+    const int my_nan = rf_stage_features(pl, F, n, i, feat);
+    constexpr int NPRE = 12;  // RF_C * ntop <= 12 * 1024 nodes per group (host keeps ntop <= 3072)
+    for (int c = 0; c < RF_C && c < n_trees; c++) {
+        const rf_tree t0 = trees[c];
+        const int cnt = t0.n_nodes < ntop ? t0.n_nodes : ntop;
+        for (int j = threadIdx.x; j < cnt; j += RF_TH) top[(size_t)c * ntop + j] = nodes[t0.node_off + j];
+    }
+    const bool any_nan = __syncthreads_or(my_nan) != 0;
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.0;
+    const int n_groups = (n_trees + RF_C - 1) / RF_C;
+    for (int g = 0; g < n_groups; g++) {
+        const int t = g * RF_C;
+        rf_tree tr[RF_C];
+#pragma unroll
+        for (int c = 0; c < RF_C; c++) tr[c] = trees[t + c < n_trees ? t + c : n_trees - 1];
+        rf_node pre[NPRE];
+        int pcnt[RF_C], poff[RF_C];
+        const bool more = t + RF_C < n_trees;
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < RF_C; c++) {
+                const bool have = t + RF_C + c < n_trees;
+                const rf_tree tnx = trees[have ? t + RF_C + c : n_trees - 1];
+                pcnt[c] = have ? (tnx.n_nodes < ntop ? tnx.n_nodes : ntop) : 0;
+                poff[c] = tnx.node_off;
+            }
+#pragma unroll
+            for (int r = 0; r < NPRE; r++) {
+                const int j = threadIdx.x + r * RF_TH;  // [0, RF_C * ntop): block c = j / ntop
+                if (j < RF_C * ntop) {
+                    const int c = j / ntop, o = j - c * ntop;
+                    int cnt = pcnt[0], off = poff[0];
+#pragma unroll
+                    for (int cc = 1; cc < RF_C; cc++)
+                        if (c == cc) { cnt = pcnt[cc]; off = poff[cc]; }
+                    if (o < cnt) pre[r] = nodes[off + o];
+                }
+            }
+        }
+        {
+            rf_node nd[RF_C];
+            int lim[RF_C], noff[RF_C];
+            lds_cfloat *lfeat = (lds_cfloat *)feat;
+            lds_cnode *ltop = (lds_cnode *)top;
+#pragma unroll
+            for (int c = 0; c < RF_C; c++) {
+                noff[c] = tr[c].node_off;
+                lim[c] = tr[c].n_nodes < ntop ? tr[c].n_nodes : ntop;
+                nd[c].thr = ltop[c * ntop].thr;
+                nd[c].bits = ltop[c * ntop].bits;
+                if (t + c >= n_trees || i >= n) nd[c].bits = RF_LEAF;  // no tree / no pixel: nothing to walk
+            }
+            if (any_nan) rf_walk_gen<true>(nd, lfeat, ltop, ntop, lim, nodes, noff);
+            else rf_walk_gen<false>(nd, lfeat, ltop, ntop, lim, nodes, noff);
+            if (i < n) {
+#pragma unroll
+                for (int c = 0; c < RF_C; c++)
+                    if (t + c < n_trees) rf_vote<NC>(nd[c], leafval, acc);
+            }
+        }
+        if (more) {
+            __syncthreads();  // every wave is done with the current blocks
+#pragma unroll
+            for (int r = 0; r < NPRE; r++) {
+                const int j = threadIdx.x + r * RF_TH;
+                if (j < RF_C * ntop) {
+                    const int c = j / ntop, o = j - c * ntop;
+                    int cnt = pcnt[0];
+#pragma unroll
+                    for (int cc = 1; cc < RF_C; cc++)
+                        if (c == cc) cnt = pcnt[cc];
+                    if (o < cnt) top[j] = pre[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (i < n) rf_finish<NC>(acc, n_trees, n_classes, classes, out, i);
+}
+
+// nodes of a tree group that fit the LDS beside the features of 1024 pixels (one 16-byte piece is kept for the dummy leaf)
+static int rf_lds_cap(int F)
+{
+    const long bytes = 160L * 1024 - 256 - (long)F * RF_TH * 4 - 16;
+    long cap = bytes / 8;
+    cap = std::min<long>(cap, 2L * RF_NPRE * RF_LT) & ~1L;
+    return (int)std::max<long>(cap, 0);
 }
 
 extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tree_off, const int32_t *left, const int32_t *right,
@@ -186,7 +410,9 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     const int64_t nn = tree_off[n_trees];
     if (nn < n_trees || nn > 0x7ffffff0) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: bad node count %lld", (long long)nn);
     std::vector<rf_node> nodes((size_t)nn);
-    std::vector<double> leaf;
+    const int NCP = n_classes <= 4 ? 4 : (n_classes <= 8 ? 8 : (n_classes <= 16 ? 16 : 32));  // row length of the vote table
+    std::vector<double> leaf((size_t)n_classes * NCP, 0.0);
+    for (int c = 0; c < n_classes; c++) leaf[(size_t)c * NCP + c] = 1.0;
     std::vector<rf_tree> trees(n_trees);
     std::vector<int> order, newid;
     for (int t = 0; t < n_trees; t++) {
@@ -212,27 +438,32 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
         if ((int)order.size() != cnt) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: tree %d has unreachable nodes", t);
         trees[t].node_off = (int)b;
         trees[t].n_nodes = cnt;
-        trees[t].leaf_off = (int)(leaf.size() / n_classes);
+        trees[t].leaf_off = 0;
         trees[t].pad = 0;
         int nleaf = 0;
         for (int h = 0; h < cnt; h++) {
             const int64_t g = b + order[h];
             rf_node &nd = nodes[(size_t)(b + h)];
             if (left[g] == -1) {
-                nd.thr = 0.f;
                 const double *v = value + (size_t)g * n_classes;
                 int ones = 0, zeros = 0, cls = 0;
                 for (int c = 0; c < n_classes; c++) {
                     if (v[c] == 1.0) { ones++; cls = c; }
                     else if (v[c] == 0.0) zeros++;
                 }
+                unsigned pay;
                 if (ones == 1 && zeros == n_classes - 1) {
-                    nd.bits = RF_LEAF | RF_PURE | ((unsigned)cls << 24);
+                    pay = (unsigned)cls;                    // the shared one-hot row of the class
                 } else {
-                    nd.bits = RF_LEAF | (unsigned)nleaf;
+                    const size_t row = leaf.size() / NCP;
+                    if (row > RF_PAY_MASK) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "forest_load: more than %u mixed leaves in the forest", RF_PAY_MASK);
+                    pay = (unsigned)row;
                     nleaf++;
-                    for (int c = 0; c < n_classes; c++) leaf.push_back(v[c]);
+                    for (int c = 0; c < NCP; c++) leaf.push_back(c < n_classes ? v[c] : 0.0);
                 }
+                const unsigned tb = RF_NAN_BITS | pay;   // the vote rides in the payload of a NaN threshold
+                memcpy(&nd.thr, &tb, 4);
+                nd.bits = RF_LEAF | RF_MISS | (unsigned)h;  // a leaf's "left child" is the leaf itself
             } else {
                 float f = (float)threshold[g];
                 if ((double)f > threshold[g]) f = nextafterf(f, -INFINITY);  // round toward -inf
@@ -242,13 +473,37 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
             }
         }
     }
-    if (leaf.empty()) leaf.push_back(0.0);
+    // ---- plan of k11_forest_lds: groups of <= RF_C consecutive trees whose nodes fit the LDS beside the features ----
+    const int cap = rf_lds_cap(n_features);
+    std::vector<rf_group> groups;
+    bool fits = true;
+    for (int t = 0; t < n_trees && fits;) {
+        rf_group g;
+        g.first = t;
+        g.node_base = trees[t].node_off & ~1;
+        g.count = 0;
+        g.n_nodes = 0;
+        while (t < n_trees && g.count < RF_C && trees[t].node_off + trees[t].n_nodes - g.node_base <= cap) {
+            g.n_nodes = trees[t].node_off + trees[t].n_nodes - g.node_base;
+            g.count++;
+            t++;
+        }
+        if (g.count == 0) fits = false;  // a single tree larger than the LDS area: the general kernel takes the forest
+        else groups.push_back(g);
+    }
+    if (!fits) groups.clear();
     forest_dev &fd = ctx->forest;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (fd.d_nodes) HIPCHK(ctx, hipFree(fd.d_nodes));
     if (fd.d_leafval) HIPCHK(ctx, hipFree(fd.d_leafval));
     if (fd.d_treeoff) HIPCHK(ctx, hipFree(fd.d_treeoff));
-    fd.d_nodes = fd.d_leafval = fd.d_treeoff = nullptr;
+    if (fd.d_groups) HIPCHK(ctx, hipFree(fd.d_groups));
+    fd.d_nodes = fd.d_leafval = fd.d_treeoff = fd.d_groups = nullptr;
+    fd.n_groups = (int)groups.size();
+    if (!groups.empty()) {
+        HIPCHK(ctx, hipMalloc(&fd.d_groups, groups.size() * sizeof(rf_group)));
+        HIPCHK(ctx, hipMemcpy(fd.d_groups, groups.data(), groups.size() * sizeof(rf_group), hipMemcpyHostToDevice));
+    }
     HIPCHK(ctx, hipMalloc(&fd.d_nodes, nodes.size() * sizeof(rf_node) + 64));
     HIPCHK(ctx, hipMalloc(&fd.d_leafval, leaf.size() * sizeof(double) + 64));
     HIPCHK(ctx, hipMalloc(&fd.d_treeoff, n_classes * sizeof(long long) + trees.size() * sizeof(rf_tree) + 64));
@@ -283,23 +538,41 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     if (n == 0) return RSSEG_OK;
     const long long *d_classes = (const long long *)fd.d_treeoff;
     const rf_tree *d_trees = (const rf_tree *)((const char *)fd.d_treeoff + fd.n_classes * sizeof(long long));
-    // workgroup size: 1024 pixels (16 waves hide the gathers below the LDS-resident top block);
-    // LDS = features TH * F * 4 B + two top blocks of ntop 8-byte nodes
-    const int TH = 1024;
-    int ntop = 4096;  // per tree; four blocks resident (two pairs)
-    while (ntop > 256 && (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node) > 150 * 1024) ntop >>= 1;
-    const size_t lds = (size_t)F * TH * 4 + 4 * (size_t)ntop * sizeof(rf_node);
-    const unsigned grid = (unsigned)ceil_div64(n, TH);
-    auto launch = [&](auto kern) -> int {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        prof_scope ps(ctx, "forest");
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TH), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees, fd.n_trees, ntop,
-                           (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
-        return RSSEG_OK;
-    };
+    const unsigned grid = (unsigned)ceil_div64(n, RF_TH);
     int rc;
-    if (fd.n_classes <= 4) rc = launch(k11_forest<4, 1024>);
-    else rc = launch(k11_forest<RF_NCMAX, 1024>);
+    if (fd.n_groups > 0) {
+        // every group of trees fits the LDS: features 1024 * F * 4 B + cap nodes + the dummy leaf
+        const int cap = rf_lds_cap(F);
+        const size_t lds = (size_t)F * RF_TH * 4 + (size_t)cap * sizeof(rf_node) + 16;
+        auto launch = [&](auto kern) -> int {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            prof_scope ps(ctx, "forest");
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_LT), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees,
+                               (const rf_group *)fd.d_groups, fd.n_groups, cap / 2, fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes,
+                               (long long *)d_out);
+            return RSSEG_OK;
+        };
+        if (fd.n_classes <= 4) rc = launch(k11_forest_lds<4>);
+        else if (fd.n_classes <= 8) rc = launch(k11_forest_lds<8>);
+        else if (fd.n_classes <= 16) rc = launch(k11_forest_lds<16>);
+        else rc = launch(k11_forest_lds<32>);
+    } else {
+        // a tree larger than the LDS area: the first ntop (breadth-first) nodes of RF_C trees in LDS, in steps of 256
+        int ntop = 3072;
+        while (ntop > 256 && (size_t)F * RF_TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node) > 158 * 1024) ntop -= 256;
+        const size_t lds = (size_t)F * RF_TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node);
+        auto launch = [&](auto kern) -> int {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            prof_scope ps(ctx, "forest");
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_TH), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees, fd.n_trees, ntop,
+                               (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
+            return RSSEG_OK;
+        };
+        if (fd.n_classes <= 4) rc = launch(k11_forest_gen<4>);
+        else if (fd.n_classes <= 8) rc = launch(k11_forest_gen<8>);
+        else if (fd.n_classes <= 16) rc = launch(k11_forest_gen<16>);
+        else rc = launch(k11_forest_gen<32>);
+    }
     if (rc != RSSEG_OK) return rc;
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

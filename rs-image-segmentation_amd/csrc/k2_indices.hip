@@ -179,7 +179,7 @@ extern "C" int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, 
     if ((((uintptr_t)d_x | (uintptr_t)d_out) & 15) != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize: planes must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
-        prof_scope ps(ctx, "indices");
+        prof_scope ps(ctx, "normalize");
         hipLaunchKernelGGL(k2_normalize, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_out, n, lo, hi, norm_den(lo, hi));
     }
     HIPCHK(ctx, hipGetLastError());
@@ -228,7 +228,7 @@ extern "C" int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, fl
     if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 3)) return rs_fail(ctx, RSSEG_ERR_INVALID, "quantize: unaligned plane");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
-        prof_scope ps(ctx, "indices");
+        prof_scope ps(ctx, "quantize");
         hipLaunchKernelGGL(k2_quantize<false>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult, 0.f, 1.f, 1.f);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -242,7 +242,7 @@ extern "C" int rsseg_normalize_quantize_u8(rsseg_ctx *ctx, const float *d_x, int
     if (((uintptr_t)d_x & 15) || ((uintptr_t)d_q & 3)) return rs_fail(ctx, RSSEG_ERR_INVALID, "normalize_quantize: unaligned plane");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
-        prof_scope ps(ctx, "indices");
+        prof_scope ps(ctx, "quantize");
         hipLaunchKernelGGL(k2_quantize<true>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult, lo, hi,
                            norm_den(lo, hi));
     }
@@ -256,7 +256,7 @@ extern "C" int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t 
     if (!d_q || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "u8_to_unit: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
-        prof_scope ps(ctx, "indices");
+        prof_scope ps(ctx, "quantize");
         hipLaunchKernelGGL(k2_u8_unit, dim3(stream_grid(n)), dim3(K2_THREADS), 0, ctx->stream, d_q, d_out, n);
     }
     HIPCHK(ctx, hipGetLastError());

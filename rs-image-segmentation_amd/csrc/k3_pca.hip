@@ -341,7 +341,7 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
         for (int b = 0; b < nb; b++) mm[2 * b] = mm[2 * b + 1] = -INFINITY;
         if (fit_n > 0) {
             {
-                prof_scope ps(ctx, "gram");
+                prof_scope ps(ctx, "range");
                 hipLaunchKernelGGL(k3_range, dim3(rgrid), dim3(PCA_THREADS), 0, ctx->stream, a, fit_off, fit_n, (float *)ctx->d_ws);
             }
             HIPCHK(ctx, hipGetLastError());

@@ -327,7 +327,21 @@ __global__ __launch_bounds__(256) void k8_filter(const uint8_t *__restrict__ q, 
             }
         }
     }
-    if (PASS == 0) mm_commit(mm, lmn, lmx);  // lanes without pixels carry +inf / -inf: they never win
+    if (PASS == 0) {
+        // one commit per WORKGROUP (a per-wave test of the global slot makes 4 M waves read one address: 2.8 ms at
+        // 16384^2); lanes without pixels carry +inf / -inf and never win
+        __shared__ float smn[4], smx[4];
+        lmn = wave_min(lmn);
+        lmx = wave_max(lmx);
+        if (lane_id() == 0) { smn[threadIdx.x >> 6] = lmn; smx[threadIdx.x >> 6] = lmx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3])), mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+            const uint32_t kmn = mm_key(mn), kmx = mm_key(mx);
+            if (kmn < __builtin_nontemporal_load(&mm[0])) atomicMin(&mm[0], kmn);
+            if (kmx > __builtin_nontemporal_load(&mm[1])) atomicMax(&mm[1], kmx);
+        }
+    }
 }
 
 // cv2.resize INTER_LINEAR float32: horizontal taps (edge taps get weight 0), vertical taps clamp rows

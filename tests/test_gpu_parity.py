@@ -528,6 +528,36 @@ def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
     assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
+def test_forest_large_trees_many_classes_and_infinities_vs_sklearn(ctx, oracle):
+    """(a) Unpruned trees with more nodes than the LDS holds (the general kernel: upper levels in LDS, deeper nodes by
+    global loads), with NaN rows; (b) 11 and 20 classes (sklearn has no class limit; the wider vote tables);
+    (c) +/-inf features walk like any other value (x <= thr), as sklearn's tree does."""
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(3)
+    Xtr = rng.random((60000, 7)).astype(np.float32)
+    ytr = rng.integers(0, 3, 60000)                         # pure noise: trees grow until every leaf is pure
+    big = RandomForestClassifier(n_estimators=6, max_depth=None, random_state=0, n_jobs=8).fit(Xtr, ytr)
+    assert max(e.tree_.node_count for e in big.estimators_) > 20000
+    X = rng.random((40001, 7)).astype(np.float32)
+    X[::41, 3] = np.nan
+    X[7::43, 0] = np.inf
+    X[9::47, 5] = -np.inf
+    ctx.forest_load(oracle.flatten_forest(big))
+    got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(7)]))
+    Xs = X.copy()
+    fin = np.isfinite(Xs) | np.isnan(Xs)
+    Xs[~fin] = np.sign(Xs[~fin]) * 3.0e38                    # sklearn refuses inf input; the same comparisons with huge values
+    assert np.array_equal(got, big.predict(Xs))
+    for ncls in (11, 20):
+        Xt = rng.random((8000, 5)).astype(np.float32)
+        yt = ((Xt[:, 1] * ncls).astype(np.int64) + (rng.random(8000) < 0.15) * rng.integers(0, ncls, 8000)) % ncls * 3 + 100  # labels 100, 103, ...
+        m = RandomForestClassifier(n_estimators=15, max_depth=10, random_state=2, n_jobs=4).fit(Xt, yt)
+        assert len(m.classes_) == ncls
+        Xp = rng.random((3001, 5)).astype(np.float32)
+        ctx.forest_load(oracle.flatten_forest(m))
+        assert np.array_equal(host(ctx.forest_predict([dev(ctx, Xp[:, i]) for i in range(5)])), m.predict(Xp)), ncls
+
+
 def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
     """One select per band (config-3 fast path) gives the same six statistics as the separate NumPy-style
     calls on the raw and on the normalised band."""
