@@ -196,6 +196,63 @@ int oracle_glcm(const uint8_t *q, int H, int W, int levels, int win, int step, i
     return err;
 }
 
+/* One angle of one window, literally: the co-occurrence COUNTS graycomatrix returns (symmetric = 0 / 1, not normed) and
+ * graycoprops' five properties of the symmetric, normalised matrix.  This is the function the published scikit-image
+ * vectors are checked against (tests/test_oracle.py::test_glcm_matches_skimage_docstring_vectors): it shares the
+ * offsets, the pair loop and the property formulas with mode 0 of oracle_glcm above.
+ * counts: levels*levels uint32 (row i = reference level, column j = neighbour level); props: contrast, dissimilarity,
+ * homogeneity, energy, correlation. */
+int oracle_glcm_angle(const uint8_t *q, int H, int W, int levels, int angle, int symmetric, uint32_t *counts, double *props)
+{
+    if (levels < 2 || levels > 256 || angle < 0 || angle > 3 || H < 2 || W < 2) return -1;
+    const int LL = levels * levels;
+    const int dr = GLCM_DR[angle], dc = GLCM_DC[angle];
+    const int r0 = dr < 0 ? -dr : 0, r1 = dr > 0 ? H - dr : H;
+    const int c0 = dc < 0 ? -dc : 0, c1 = dc > 0 ? W - dc : W;
+    uint32_t *G = (uint32_t *)calloc(LL, sizeof(uint32_t));
+    double *P = (double *)malloc(sizeof(double) * LL);
+    if (!G || !P) return -2;
+    for (int r = r0; r < r1; r++)
+        for (int c = c0; c < c1; c++) {
+            int i = q[(size_t)r * W + c], j = q[(size_t)(r + dr) * W + (c + dc)];
+            if (i >= levels || j >= levels) continue;
+            G[i * levels + j]++;
+        }
+    double total = 0.0;
+    for (int i = 0; i < levels; i++)
+        for (int j = 0; j < levels; j++) {
+            counts[i * levels + j] = symmetric ? G[i * levels + j] + G[j * levels + i] : G[i * levels + j];
+            P[i * levels + j] = (double)(G[i * levels + j] + G[j * levels + i]);
+            total += P[i * levels + j];
+        }
+    if (total == 0.0) total = 1.0;
+    for (int t = 0; t < LL; t++) P[t] /= total;
+    double con = 0, dis = 0, hom = 0, asm_ = 0, mi = 0, mj = 0;
+    for (int i = 0; i < levels; i++)
+        for (int j = 0; j < levels; j++) {
+            double p = P[i * levels + j], dd = (double)(i - j);
+            con += p * dd * dd;
+            dis += p * fabs(dd);
+            hom += p * (1.0 / (1.0 + dd * dd));
+            asm_ += p * p;
+            mi += i * p;
+            mj += j * p;
+        }
+    double vi = 0, vj = 0, cov = 0;
+    for (int i = 0; i < levels; i++)
+        for (int j = 0; j < levels; j++) {
+            double p = P[i * levels + j];
+            vi += p * (i - mi) * (i - mi);
+            vj += p * (j - mj) * (j - mj);
+            cov += p * (i - mi) * (j - mj);
+        }
+    double si = sqrt(vi), sj = sqrt(vj);
+    props[0] = con; props[1] = dis; props[2] = hom; props[3] = sqrt(asm_);
+    props[4] = (si < 1e-15 || sj < 1e-15) ? 1.0 : cov / (si * sj);
+    free(G); free(P);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Random-forest inference.
  * Reference: modules/supervised_classifiers.py:99-115 (predict_image) and

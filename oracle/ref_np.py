@@ -379,6 +379,20 @@ def glcm_small_maps(q: np.ndarray, levels: int, window_size: int, step_size: int
     return dict(zip(["contrast", "dissimilarity", "homogeneity", "energy", "correlation"], outs))
 
 
+def glcm_angle(q: np.ndarray, levels: int, angle: int, symmetric: bool = True):
+    """One angle (0: 0 deg, 1: 45, 2: 90, 3: 135; distance 1) of the whole image as one window: graycomatrix counts and
+    graycoprops' five properties of the symmetric normalised matrix (oracle.c::oracle_glcm_angle)."""
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    H, W = q.shape
+    counts = np.zeros((levels, levels), np.uint32)
+    props = np.zeros(5, np.float64)
+    rc = lib().oracle_glcm_angle(q.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), H, W, levels, angle, int(symmetric),
+                                 counts.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), props.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    if rc != 0:
+        raise ValueError(f"oracle_glcm_angle rc={rc}")
+    return counts, dict(zip(["contrast", "dissimilarity", "homogeneity", "energy", "correlation"], props))
+
+
 def calculate_glcm_features(band, levels=32, window_size=21, step_size=21, mode: int = 1):
     """indices.py:248-318 (distances=[1], angles=[0, pi/4, pi/2, 3pi/4] are the only values the
     reference ever passes)."""
