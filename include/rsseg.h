@@ -118,6 +118,9 @@ int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, f
  * If lohi == NULL the bands are taken as already normalised. */
 int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
                                float *const *d_out, float *const *d_norm);
+/* The same with calculate_evi's coefficients evi_coef[4] = {L, C1, C2, G} (indices.py:73; NULL = the defaults 1, 6, 7.5, 2.5). */
+int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
+                                   float *const *d_out, float *const *d_norm, const float *evi_coef);
 
 /* ---- K3: PCA ------------------------------------------------------------------------------ */
 /* perform_pca (indices.py:205-246): RobustScaler transform x' = (float)((double)(x - center) /
@@ -257,12 +260,35 @@ int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tree_off, cons
  * (modules/features/extract.py:690-719): d_planes[F] float32 feature planes -> int64 class per pixel. */
 int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes, int F, int64_t n, int64_t *d_out);
 
+/* ---- K12: rule-based classification --------------------------------------- */
+/* threshold_segmentation (modules/features/extract.py:344-404, otsu=False): NaN counts as 0, then d_out = 1 where
+ * lo < x < hi, else 0 (pass -INFINITY / INFINITY for `x > t` / `x < t`). */
+int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, uint8_t *d_out);
+/* Mask algebra of extract_builtup_by_threshold / extract_bareland_by_rule (extract.py:447-505) on 0 / 1 planes:
+ * op 0: a & b, 1: a | b, 2: a & !b, 3: !a (d_b may be NULL).  d_out may alias an input. */
+int rsseg_mask_op_u8(rsseg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int64_t n, int op, uint8_t *d_out);
+/* final_map[mask == 1] = value, or only where final_map == 0 (scripts/3_classification.py:361-363, 373). */
+int rsseg_mask_paint_u8(rsseg_ctx *ctx, uint8_t *d_map, const uint8_t *d_mask, int64_t n, int value, int only_unset);
+/* cv2.morphologyEx / erode / dilate with cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)), k in {3, 5}, on a uint8
+ * plane (advanced_post_processing, extract.py:311-313, 334-336): op = RSSEG_MORPH_ERODE / DILATE / OPEN / CLOSE. */
+int rsseg_morph_ellipse_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out);
+/* scipy.ndimage.label(mask, structure=ones((3,3))) + the np.bincount area filter (extract.py:319-329): d_out = mask
+ * without its 8-connected components of fewer than min_area pixels.  Whole raster on one GPU (components cross
+ * stripes, so this operator is not row-sharded). */
+int rsseg_remove_small_components_u8(rsseg_ctx *ctx, const uint8_t *d_mask, int H, int W, int min_area, uint8_t *d_out);
+
 /* ---- host-only helper (no GPU needed) ------------------------------------------------------- */
 /* The random draws of k-means++ as the library makes them (numpy RandomState(seed): MT19937, random_sample,
  * RandomState.choice over n equal weights — sklearn/cluster/_kmeans.py:213-270): *center_id = index of the first
  * centre, uniforms[(k-1) * (2 + floor(ln k))] = the uniform(size=L) draws of the later rounds.  Used by the CPU test
  * suite to pin the generator against NumPy. */
 int rsseg_host_kmeans_draws(uint32_t seed, int64_t n, int dtype, int k, int64_t *center_id, double *uniforms);
+/* TIFF LZW (TIFF 6.0 section 13, as libtiff / GDAL write it: MSB-first codes of 9..12 bits, early change) for the GeoTIFF
+ * outputs the reference writes with rasterio compress='lzw' (scripts/2_feature_extraction.py:239-258,
+ * scripts/3_classification.py:509-538); called per strip / tile by rsseg/tiff.py.  Return the number of bytes produced,
+ * or a negative value (-2: output buffer too small, -3: corrupt stream). */
+int64_t rsseg_host_lzw_encode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap);
+int64_t rsseg_host_lzw_decode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -443,6 +443,91 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
 
 
 # --------------------------------------------------------------------------------------------
+# rule-based classification   (modules/features/extract.py:299-505; scripts/3_classification.py:335-375)
+# scipy.ndimage.label is the reference's own dependency and is installed: the component filter below CALLS it, so
+# that part of the oracle is the real library.  cv2.morphologyEx with cv2.getStructuringElement(MORPH_ELLIPSE) is
+# restated (cv2 absent): (3,3) = cross, (5,5) = 5x5 without the corner pairs; out-of-image taps never win.
+# --------------------------------------------------------------------------------------------
+def ellipse_element(k: int) -> np.ndarray:
+    if k == 3:
+        return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+    if k == 5:
+        return np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)
+    raise ValueError(k)
+
+
+def morph_ellipse(mask: np.ndarray, k: int, op: str) -> np.ndarray:
+    se = ellipse_element(k)
+    r = k // 2
+    H, W = mask.shape
+
+    def erode(x):
+        p = np.pad(x, r, mode="constant", constant_values=255)
+        o = np.full((H, W), 255, np.uint8)
+        for dy in range(k):
+            for dx in range(k):
+                if se[dy, dx]:
+                    o = np.minimum(o, p[dy:dy + H, dx:dx + W])
+        return o
+
+    def dilate(x):
+        p = np.pad(x, r, mode="constant", constant_values=0)
+        o = np.zeros((H, W), np.uint8)
+        for dy in range(k):
+            for dx in range(k):
+                if se[dy, dx]:
+                    o = np.maximum(o, p[dy:dy + H, dx:dx + W])
+        return o
+
+    x = mask.astype(np.uint8)
+    return {"erosion": lambda: erode(x), "dilation": lambda: dilate(x), "opening": lambda: dilate(erode(x)),
+            "closing": lambda: erode(dilate(x))}[op]()
+
+
+def advanced_post_processing(binary_mask: np.ndarray, min_area=100, smooth_kernel_size=3) -> np.ndarray:
+    """extract.py:299-341 (odd kernel sizes)."""
+    from scipy import ndimage
+    m = morph_ellipse(binary_mask.astype(np.uint8), smooth_kernel_size, "closing")
+    if min_area > 0:
+        lab, nf = ndimage.label(m, structure=np.ones((3, 3)))
+        if nf > 0:
+            area = np.bincount(lab.ravel())
+            rm = np.where((area < min_area) & (area > 0))[0]
+            if rm.size > 0:
+                m[np.isin(lab, rm)] = 0
+    return morph_ellipse(m, smooth_kernel_size, "opening")
+
+
+def rule_based_classification(features: dict) -> np.ndarray:
+    """scripts/3_classification.py:335-375 with the extract_* functions of extract.py:406-505 inlined."""
+    h, w = features["height"], features["width"]
+    n = h * w
+
+    def thr(x, t, above=True):
+        x = np.nan_to_num(x, nan=0.0)
+        return (x > t).astype(np.uint8) if above else (x < t).astype(np.uint8)
+
+    ndvi, ndbi = features.get("ndvi"), features.get("ndbi")
+    final = np.zeros((h, w), np.uint8)
+    veg = advanced_post_processing(thr(ndvi, 0.25), int(n * 0.0005), 3)
+    if features.get("mndwi") is not None:
+        water = advanced_post_processing(thr(features["mndwi"], 0.1), int(n * 0.0002), 3)
+    else:
+        water = advanced_post_processing(thr(features["ndwi"], 0.05), int(n * 0.0002), 3)
+    built = advanced_post_processing(np.logical_and(thr(ndbi, 0.0), thr(ndvi, 0.2, above=False)).astype(np.uint8), int(n * 0.001), 5)
+    final[built == 1] = 3
+    final[veg == 1] = 1
+    final[water == 1] = 2
+    excl = (final == 1) | (final == 2) | (final == 3)
+    bare = np.logical_not(excl).astype(np.uint8)
+    bare = np.logical_and(bare, np.logical_and(ndvi > -0.1, ndvi < 0.2)).astype(np.uint8)
+    bare = np.logical_and(bare, np.logical_and(ndbi > -0.2, ndbi < 0.2)).astype(np.uint8)
+    bare = advanced_post_processing(bare, int(n * 0.0005), 3)
+    final[(bare == 1) & (final == 0)] = 4
+    return final
+
+
+# --------------------------------------------------------------------------------------------
 # KMeans   (modules/features/extract.py:508-581 -> oracle.c)
 # --------------------------------------------------------------------------------------------
 def kmeans_random_draws(n: int, k: int, dtype) -> Tuple[int, np.ndarray]:

@@ -58,6 +58,22 @@
 #define A_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 8, 6\n"
 #define A_FMAF32(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define A_CVTF64(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
+#define A_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define A_LSHL(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define A_OR3(i) "v_or3_b32 %" #i ", %" #i ", %8, %9\n"
+#define A_DOT2(i) "v_dot2_u32_u16 %" #i ", %" #i ", %8, %9\n"
+#define A_ADD64E(i) "v_add_u32_e64 %" #i ", %" #i ", %8\n"
+#define A_CNDMASK(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define A_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
+#define A_CVTPK(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+VALU_KERNEL(k_xor_b32, A_XOR, unsigned)
+VALU_KERNEL(k_lshlrev_b32, A_LSHL, unsigned)
+VALU_KERNEL(k_or3_b32, A_OR3, unsigned)
+VALU_KERNEL(k_dot2_u32_u16, A_DOT2, unsigned)
+VALU_KERNEL(k_add_u32_e64, A_ADD64E, unsigned)
+VALU_KERNEL(k_cndmask_b32, A_CNDMASK, unsigned)
+VALU_KERNEL(k_mul_lo_u32, A_MULLO, unsigned)
+VALU_KERNEL(k_cvt_f32_u32, A_CVTPK, unsigned)
 VALU_KERNEL(k_pk_min_u16, A_PKMIN, unsigned)
 VALU_KERNEL(k_pk_max_u16, A_PKMAX, unsigned)
 VALU_KERNEL(k_pk_add_u16, A_PKADD, unsigned)
@@ -93,6 +109,10 @@ VALU_KERNEL(k_mad_u32_u24, A_CVTF64, unsigned)
         if ((threadIdx.x & 63) == 0) t[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                      \
         if (a0 == 0.12345) sink[0] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);                                    \
     }
+#define A_LDEXP64(i) "v_ldexp_f64 %" #i ", %" #i ", 1\n"
+#define A_LSHLADD64(i) "v_lshl_add_u64 %" #i ", %" #i ", 0, %8\n"
+VALU64_KERNEL(k_ldexp_f64, A_LDEXP64)
+VALU64_KERNEL(k_lshl_add_u64, A_LSHLADD64)
 #define A_FMA64(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
 #define A_ADD64(i) "v_add_f64 %" #i ", %" #i ", %9\n"
 #define A_MUL64(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
@@ -160,7 +180,9 @@ int main()
                         {"v_perm_b32", k_perm_b32}, {"v_sad_u8", k_sad_u8}, {"v_dot4_u32_u8", k_dot4_u32_u8}, {"v_add3_u32", k_add3_u32},
                         {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_bfe_u32", k_bfe_u32},
                         {"v_fma_f32", k_fma_f32}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64},
-                        {"v_mul_f64", k_mul_f64}};
+                        {"v_mul_f64", k_mul_f64}, {"v_xor_b32", k_xor_b32}, {"v_lshlrev_b32", k_lshlrev_b32}, {"v_or3_b32", k_or3_b32},
+                        {"v_dot2_u32_u16", k_dot2_u32_u16}, {"v_add_u32_e64", k_add_u32_e64}, {"v_cndmask_b32", k_cndmask_b32},
+                        {"v_mul_lo_u32", k_mul_lo_u32}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_ldexp_f64", k_ldexp_f64}, {"v_lshl_add_u64", k_lshl_add_u64}};
     const int nent = sizeof(ents) / sizeof(ents[0]);
     for (int e = 0; e < nent; e++) {
         printf("  \"%s\": {", ents[e].name);

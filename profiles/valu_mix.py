@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""VALU issue bound of k4_glcm_thread<7,3> from (a) the static instruction histogram of the kernel
+(profiles/r02_glcm_thread_7_3_valu_hist.txt: disassembly of the gfx950 code object, `grep v_ | uniq -c`) and
+(b) the measured issue cost of each instruction class at 4 waves per SIMD (profiles/r02_ubench.json, produced by
+profiles/ubench/ubench.hip on an MI355X).  Writes profiles/r02_valu_issue.json, which bench.py reads for the
+roofline entry of the texture kernel:  frac = waves * issue_cycles_per_wave / (1024 SIMDs * 2.4 GHz * measured time).
+
+Measured classes (cycles per wave64 instruction on one SIMD, 4 waves per SIMD, independent streams):
+  fast  ~1.96   v_add_u32 / v_sub / v_and / v_or / v_xor / v_mov / v_fma_f32 (either encoding)
+  slow  ~3.24   shifts, v_pk_* (packed 16-bit), v_perm, v_sad_u8, v_dot*, v_add3, v_or3, v_lshl_add, v_bfe, v_mad*,
+                v_mul_lo, conversions and every float64 instruction
+An instruction that was not measured is priced as slow."""
+import json
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ub = json.load(open(os.path.join(HERE, "r02_ubench.json")))["valu"]
+fast = min(v["4_waves_per_simd"] for k, v in ub.items() if k in ("v_add_u32", "v_and_b32", "v_xor_b32"))
+slow = max(v["4_waves_per_simd"] for k, v in ub.items() if k in ("v_pk_min_u16", "v_perm_b32", "v_fma_f64", "v_lshlrev_b32"))
+FAST = re.compile(r"^v_(add_u32|add_co_u32|addc_co_u32|sub_u32|sub_co_u32|subb_co_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32|mov_b32|mov_b64|fma_f32|add_f32|mul_f32|max_f32|min_f32)(_e32|_e64)?$")
+hist = []
+for line in open(os.path.join(HERE, "r02_glcm_thread_7_3_valu_hist.txt")):
+    n, op = line.split()
+    hist.append((op, int(n)))
+n_fast = sum(n for op, n in hist if FAST.match(op))
+n_slow = sum(n for op, n in hist if not FAST.match(op))
+cycles = n_fast * fast + n_slow * slow
+out = {"source": "profiles/ubench/ubench.hip on MI355X + static histogram of the gfx950 code object",
+       "cost_fast_cycles": fast, "cost_slow_cycles": slow,
+       "glcm_thread_7_3": {"valu_static": n_fast + n_slow, "fast": n_fast, "slow": n_slow, "issue_cycles_per_wave": round(cycles, 1),
+                           "packed16_insts": sum(n for op, n in hist if op.startswith("v_pk_")),
+                           "f64_insts": sum(n for op, n in hist if "f64" in op)}}
+json.dump(out, open(os.path.join(HERE, "r02_valu_issue.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

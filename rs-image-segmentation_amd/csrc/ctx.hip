@@ -301,3 +301,125 @@ extern "C" int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
     return RSSEG_OK;
 }
+
+// ---- host-only helpers: TIFF LZW (TIFF 6.0 section 13; the variant GDAL / libtiff write and read) -----------------
+// The reference asks rasterio for compress='lzw' (scripts/2_feature_extraction.py:239-258, scripts/3_classification.py:
+// 509-538); rsseg/tiff.py calls these per strip / tile.  Codes are packed MSB first, 9..12 bits, ClearCode 256,
+// EndOfInformation 257, the code width grows one code early ("early change"), the table is cleared at 4094 entries.
+extern "C" int64_t rsseg_host_lzw_encode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap)
+{
+    if (!in || !out || n < 0 || cap < 16) return -1;
+    // open-addressing hash of (prefix code, byte) -> code
+    const int HSIZE = 9001;
+    std::vector<int32_t> hkey(HSIZE, -1);
+    std::vector<uint16_t> hval(HSIZE, 0);
+    int64_t op = 0;
+    uint64_t acc = 0;
+    int nacc = 0, nbits = 9, free_ent = 258;
+    auto put = [&](int code) -> bool {
+        acc = (acc << nbits) | (uint64_t)code;
+        nacc += nbits;
+        while (nacc >= 8) {
+            if (op >= cap) return false;
+            out[op++] = (uint8_t)(acc >> (nacc - 8));
+            nacc -= 8;
+        }
+        return true;
+    };
+    auto reset = [&]() {
+        std::fill(hkey.begin(), hkey.end(), -1);
+        free_ent = 258;
+        nbits = 9;
+    };
+    if (!put(256)) return -2;
+    if (n == 0) {
+        if (!put(257)) return -2;
+        if (nacc > 0) { if (op >= cap) return -2; out[op++] = (uint8_t)(acc << (8 - nacc)); }
+        return op;
+    }
+    int ent = in[0];
+    for (int64_t i = 1; i < n; i++) {
+        const int c = in[i];
+        const int32_t key = (ent << 8) | c;
+        int h = (int)(((uint32_t)key * 2654435761u) % (uint32_t)HSIZE);
+        bool found = false;
+        while (hkey[h] != -1) {
+            if (hkey[h] == key) { found = true; break; }
+            if (++h == HSIZE) h = 0;
+        }
+        if (found) { ent = hval[h]; continue; }
+        if (!put(ent)) return -2;
+        ent = c;
+        hkey[h] = key;
+        hval[h] = (uint16_t)free_ent++;
+        if (free_ent == 4094) {          // table full: ClearCode, start over
+            if (!put(256)) return -2;
+            reset();
+        } else if (free_ent > (1 << nbits) - 1)
+            nbits++;
+    }
+    if (!put(ent)) return -2;
+    // libtiff's LZWPostEncode: the last code also counts toward the width of EndOfInformation
+    free_ent++;
+    if (free_ent == 4094) { if (!put(256)) return -2; nbits = 9; }
+    else if (free_ent > (1 << nbits) - 1) nbits++;
+    if (!put(257)) return -2;
+    if (nacc > 0) { if (op >= cap) return -2; out[op++] = (uint8_t)(acc << (8 - nacc)); }
+    return op;
+}
+
+extern "C" int64_t rsseg_host_lzw_decode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap)
+{
+    if (!in || !out || n < 0 || cap < 0) return -1;
+    std::vector<uint16_t> prefix(4096, 0), length(4096, 0);
+    std::vector<uint8_t> suffix(4096, 0), first(4096, 0);
+    for (int i = 0; i < 256; i++) { suffix[i] = first[i] = (uint8_t)i; length[i] = 1; }
+    int64_t ip = 0, op = 0;
+    uint64_t acc = 0;
+    int nacc = 0, nbits = 9, free_ent = 258, old = -1;
+    auto get = [&]() -> int {
+        while (nacc < nbits) {
+            if (ip >= n) return 257;
+            acc = (acc << 8) | in[ip++];
+            nacc += 8;
+        }
+        const int code = (int)((acc >> (nacc - nbits)) & ((1u << nbits) - 1));
+        nacc -= nbits;
+        return code;
+    };
+    auto emit = [&](int code) -> bool {
+        const int len = length[code];
+        if (op + len > cap) return false;
+        int c = code;
+        for (int k = len - 1; k >= 0; k--) { out[op + k] = suffix[c]; c = prefix[c]; }
+        op += len;
+        return true;
+    };
+    for (;;) {
+        int code = get();
+        if (code == 257) break;
+        if (code == 256) {
+            free_ent = 258;
+            nbits = 9;
+            code = get();
+            if (code == 257) break;
+            if (code > 255) return -3;
+            if (!emit(code)) return -2;
+            old = code;
+            continue;
+        }
+        if (old < 0) return -3;
+        if (code < free_ent) {
+            if (!emit(code)) return -2;
+            if (free_ent < 4096) { prefix[free_ent] = (uint16_t)old; suffix[free_ent] = first[code]; first[free_ent] = first[old]; length[free_ent] = length[old] + 1; free_ent++; }
+        } else if (code == free_ent && free_ent < 4096) {
+            prefix[free_ent] = (uint16_t)old; suffix[free_ent] = first[old]; first[free_ent] = first[old]; length[free_ent] = length[old] + 1;
+            free_ent++;
+            if (!emit(code)) return -2;
+        } else
+            return -3;
+        old = code;
+        if (free_ent > (1 << nbits) - 2 && nbits < 12) nbits++;
+    }
+    return op;
+}

@@ -1,0 +1,230 @@
+// K12 — rule-based classification: index thresholds, elliptical binary morphology and the
+// 8-connected component area filter of advanced_post_processing.
+//
+// Replaces (reference modules/features/extract.py):
+//   threshold_segmentation          :344-404   NaN -> 0, then x > t / x < t (the Otsu branch is not used by the stage)
+//   advanced_post_processing        :299-341   cv2.morphologyEx(CLOSE, ELLIPSE k) -> scipy.ndimage.label(structure=ones(3,3))
+//                                              + np.bincount area filter -> cv2.morphologyEx(OPEN, ELLIPSE k)
+//   extract_*_by_threshold / _rule  :406-505   mask algebra (scripts/3_classification.py:335-375 merges them by priority)
+// Masks are uint8 planes holding 0 / 1.  cv2.getStructuringElement(MORPH_ELLIPSE): (3,3) is the cross, (5,5) the 5x5
+// square without its four corner pairs (rows 01110 are 00100: see rf_se below); cv2's default morphology border never
+// wins (erode: outside = max, dilate: outside = min), i.e. out-of-image taps are skipped.
+// Connected components: lock-free union-find over the image (Playne & Hawick's atomicMin union on a parent plane):
+// one pass unites every foreground pixel with its W / NW / N / NE foreground neighbours (8-connectivity needs only
+// these four), a second pass flattens, a third counts the pixels of every root, a fourth keeps components of at least
+// min_area pixels.  The result depends on connectivity and areas only, so it equals scipy's label + bincount filter
+// whatever order the atomics land in.
+#include "common.h"
+
+#define K12_THREADS 256
+
+static inline unsigned k12_grid(int64_t n) { return (unsigned)std::min<int64_t>(65535 * 16, std::max<int64_t>(1, ceil_div64(n, K12_THREADS))); }
+
+// out = 1 where lo < x < hi (NaN counts as 0, extract.py:354-356); use -inf / +inf for one-sided thresholds
+__global__ __launch_bounds__(K12_THREADS) void k12_band(const float *__restrict__ x, int64_t n, float lo, float hi, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        float v = x[i];
+        if (v != v) v = 0.f;
+        out[i] = (v > lo && v < hi) ? 1 : 0;
+    }
+}
+
+// op 0: a & b, 1: a | b, 2: a & !b, 3: !a
+__global__ __launch_bounds__(K12_THREADS) void k12_maskop(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t n, int op,
+                                                          uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        const bool x = a[i] != 0, y = b ? b[i] != 0 : false;
+        out[i] = (op == 0 ? (x && y) : op == 1 ? (x || y) : op == 2 ? (x && !y) : !x) ? 1 : 0;
+    }
+}
+
+// map[mask == 1 (and, if only_unset, map == 0)] = value   (scripts/3:361-363, 373)
+__global__ __launch_bounds__(K12_THREADS) void k12_paint(uint8_t *__restrict__ map, const uint8_t *__restrict__ mask, int64_t n, int value, int only_unset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS)
+        if (mask[i] == 1 && (!only_unset || map[i] == 0)) map[i] = (uint8_t)value;
+}
+
+// binary erode (MODE 0) / dilate (MODE 1) with cv2's elliptical structuring element, K = 3 or 5
+template <int K, int MODE>
+__global__ __launch_bounds__(K12_THREADS) void k12_morph(const uint8_t *__restrict__ q, int H, int W, uint8_t *__restrict__ out)
+{
+    constexpr int R = K / 2;
+    const int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        int acc = MODE == 0 ? 255 : 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++) {
+            // ellipse rows: K = 3: 010 / 111 / 010; K = 5: 00100 / 11111 / 11111 / 11111 / 00100
+            const int half = (dy == -R || dy == R) ? 0 : R;
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (dx < -half || dx > half) continue;
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const int v = q[(size_t)yy * W + xx];
+                acc = MODE == 0 ? (v < acc ? v : acc) : (v > acc ? v : acc);
+            }
+        }
+        out[i] = (uint8_t)acc;
+    }
+}
+
+// ---- connected components ----
+__device__ __forceinline__ int cc_find(const int *L, int i)
+{
+    int p = L[i];
+    while (p != i) { i = p; p = L[i]; }
+    return i;
+}
+__device__ __forceinline__ void cc_union(int *L, int a, int b)
+{
+    bool done;
+    do {
+        a = cc_find(L, a);
+        b = cc_find(L, b);
+        if (a < b) {
+            const int old = atomicMin(&L[b], a);
+            done = old == b;
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&L[a], b);
+            done = old == a;
+            a = old;
+        } else
+            done = true;
+    } while (!done);
+}
+__global__ __launch_bounds__(K12_THREADS) void k12_cc_init(const uint8_t *__restrict__ m, int64_t n, int *__restrict__ L, int *__restrict__ area)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        L[i] = m[i] ? (int)i : -1;
+        area[i] = 0;
+    }
+}
+__global__ __launch_bounds__(K12_THREADS) void k12_cc_union(const uint8_t *__restrict__ m, int H, int W, int *__restrict__ L)
+{
+    const int64_t n = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        if (!m[i]) continue;
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        if (x > 0 && m[i - 1]) cc_union(L, (int)i, (int)i - 1);
+        if (y > 0) {
+            if (m[i - W]) cc_union(L, (int)i, (int)(i - W));
+            if (x > 0 && m[i - W - 1]) cc_union(L, (int)i, (int)(i - W - 1));
+            if (x + 1 < W && m[i - W + 1]) cc_union(L, (int)i, (int)(i - W + 1));
+        }
+    }
+}
+__global__ __launch_bounds__(K12_THREADS) void k12_cc_count(int64_t n, int *__restrict__ L, int *__restrict__ area)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        if (L[i] < 0) continue;
+        const int r = cc_find(L, (int)i);
+        L[i] = r;                      // roots never change after the union pass, so flattening here is safe
+        atomicAdd(&area[r], 1);
+    }
+}
+__global__ __launch_bounds__(K12_THREADS) void k12_cc_filter(int64_t n, const int *__restrict__ L, const int *__restrict__ area, int min_area,
+                                                             uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
+        const int r = L[i];
+        // a pixel flattened before its root received its last child still points INTO its component: walk up (read-only)
+        out[i] = (r >= 0 && area[cc_find(L, r)] >= min_area) ? 1 : 0;
+    }
+}
+
+static int k12_check(rsseg_ctx *ctx, const char *what, const void *a, const void *out, int H, int W)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!a || !out || H < 1 || W < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "%s: bad arguments", what);
+    if ((int64_t)H * W > 0x7fffffff) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "%s: more than 2^31 pixels", what);
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, uint8_t *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_x || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "threshold: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n) hipLaunchKernelGGL(k12_band, dim3(k12_grid(n)), dim3(K12_THREADS), 0, ctx->stream, d_x, n, lo, hi, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_mask_op_u8(rsseg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int64_t n, int op, uint8_t *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_a || !d_out || n < 0 || op < 0 || op > 3 || (op < 3 && !d_b)) return rs_fail(ctx, RSSEG_ERR_INVALID, "mask_op: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n) hipLaunchKernelGGL(k12_maskop, dim3(k12_grid(n)), dim3(K12_THREADS), 0, ctx->stream, d_a, d_b, n, op, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_mask_paint_u8(rsseg_ctx *ctx, uint8_t *d_map, const uint8_t *d_mask, int64_t n, int value, int only_unset)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_map || !d_mask || n < 0 || value < 0 || value > 255) return rs_fail(ctx, RSSEG_ERR_INVALID, "mask_paint: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n) hipLaunchKernelGGL(k12_paint, dim3(k12_grid(n)), dim3(K12_THREADS), 0, ctx->stream, d_map, d_mask, n, value, only_unset);
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+template <int MODE> static int k12_morph_launch(rsseg_ctx *ctx, const uint8_t *in, int H, int W, int k, uint8_t *out)
+{
+    const unsigned g = k12_grid((int64_t)H * W);
+    if (k == 3) hipLaunchKernelGGL((k12_morph<3, MODE>), dim3(g), dim3(K12_THREADS), 0, ctx->stream, in, H, W, out);
+    else hipLaunchKernelGGL((k12_morph<5, MODE>), dim3(g), dim3(K12_THREADS), 0, ctx->stream, in, H, W, out);
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_morph_ellipse_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out)
+{
+    RSCHK(k12_check(ctx, "morph_ellipse", d_q, d_out, H, W));
+    if (k != 3 && k != 5) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "morph_ellipse: kernel size %d not in {3,5}", k);
+    if (d_q == d_out) return rs_fail(ctx, RSSEG_ERR_INVALID, "morph_ellipse: in-place not supported");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (op == RSSEG_MORPH_ERODE) RSCHK(k12_morph_launch<0>(ctx, d_q, H, W, k, d_out));
+    else if (op == RSSEG_MORPH_DILATE) RSCHK(k12_morph_launch<1>(ctx, d_q, H, W, k, d_out));
+    else if (op == RSSEG_MORPH_OPEN || op == RSSEG_MORPH_CLOSE) {
+        RSCHK(ws_reserve(ctx, (size_t)H * W + 64));
+        uint8_t *tmp = (uint8_t *)ctx->d_ws;
+        if (op == RSSEG_MORPH_OPEN) {
+            RSCHK(k12_morph_launch<0>(ctx, d_q, H, W, k, tmp));
+            RSCHK(k12_morph_launch<1>(ctx, tmp, H, W, k, d_out));
+        } else {
+            RSCHK(k12_morph_launch<1>(ctx, d_q, H, W, k, tmp));
+            RSCHK(k12_morph_launch<0>(ctx, tmp, H, W, k, d_out));
+        }
+    } else
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "morph_ellipse: unknown operation %d", op);
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_remove_small_components_u8(rsseg_ctx *ctx, const uint8_t *d_mask, int H, int W, int min_area, uint8_t *d_out)
+{
+    RSCHK(k12_check(ctx, "remove_small_components", d_mask, d_out, H, W));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n = (int64_t)H * W;
+    RSCHK(ws_reserve(ctx, sizeof(int) * 2 * (size_t)n + 256));
+    int *L = (int *)ctx->d_ws, *area = L + n;
+    const unsigned g = k12_grid(n);
+    {
+        prof_scope ps(ctx, "components");
+        hipLaunchKernelGGL(k12_cc_init, dim3(g), dim3(K12_THREADS), 0, ctx->stream, d_mask, n, L, area);
+        hipLaunchKernelGGL(k12_cc_union, dim3(g), dim3(K12_THREADS), 0, ctx->stream, d_mask, H, W, L);
+        hipLaunchKernelGGL(k12_cc_count, dim3(g), dim3(K12_THREADS), 0, ctx->stream, n, L, area);
+        hipLaunchKernelGGL(k12_cc_filter, dim3(g), dim3(K12_THREADS), 0, ctx->stream, n, (const int *)L, (const int *)area, min_area, d_out);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}

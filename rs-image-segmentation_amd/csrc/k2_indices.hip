@@ -25,19 +25,20 @@ struct k2_args {
     float *norm[5];
     float lo[5], hi[5], den[5];
     int normalise;
+    float evi_L, evi_C1, evi_C2, evi_G;   // calculate_evi's coefficients (defaults 1, 6, 7.5, 2.5), as float32 like NumPy's weak scalars
 };
 
 // o: ndvi, evi, msavi, ndwi, mndwi, ndbi, bsi
-__device__ __forceinline__ void k2_pixel(const float nb[5], float o[7])
+__device__ __forceinline__ void k2_pixel(const k2_args &a, const float nb[5], float o[7])
 {
     const float blue = nb[0], green = nb[1], red = nb[2], nir = nb[3], swir = nb[4];
     const float nmr = nir - red;
     o[0] = ratio_index(nmr, nir + red);
     {   // indices.py:86-93  nir + C1*red - C2*blue + L ;  G*(nir-red)/den
-        float den = nir + 6.0f * red;
-        den = den - 7.5f * blue;
-        den = den + 1.0f;
-        o[1] = ratio_index(2.5f * nmr, den);
+        float den = nir + a.evi_C1 * red;
+        den = den - a.evi_C2 * blue;
+        den = den + a.evi_L;
+        o[1] = ratio_index(a.evi_G * nmr, den);
     }
     {   // indices.py:109-112  (a - sqrt(a**2 - 8*(nir-red))) / 2
         const float a = 2.0f * nir + 1.0f;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
             for (int p = 0; p < 4; p++) nb[p][j] = a.normalise ? norm1(v[p], a.lo[j], a.hi[j], a.den[j]) : v[p];
         }
 #pragma unroll
-        for (int p = 0; p < 4; p++) k2_pixel(nb[p], o[p]);
+        for (int p = 0; p < 4; p++) k2_pixel(a, nb[p], o[p]);
         if (MM) {
 #pragma unroll
             for (int j = 0; j < 7; j++)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
             float v = a.band[j][t];
             nb[j] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
         }
-        k2_pixel(nb, o);
+        k2_pixel(a, nb, o);
         if (MM) {
 #pragma unroll
             for (int j = 0; j < 7; j++) {
@@ -189,6 +190,12 @@ extern "C" int rsseg_normalize_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, 
 extern "C" int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
                                           float *const *d_out, float *const *d_norm)
 {
+    return rsseg_spectral_indices_evi_f32(ctx, d_bands, n, lohi, d_out, d_norm, nullptr);
+}
+
+extern "C" int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
+                                              float *const *d_out, float *const *d_norm, const float *evi_coef)
+{
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_bands || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: bad arguments");
     k2_args a;
@@ -205,6 +212,10 @@ extern "C" int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_
         }
     }
     a.normalise = lohi != nullptr;
+    a.evi_L = evi_coef ? evi_coef[0] : 1.0f;
+    a.evi_C1 = evi_coef ? evi_coef[1] : 6.0f;
+    a.evi_C2 = evi_coef ? evi_coef[2] : 7.5f;
+    a.evi_G = evi_coef ? evi_coef[3] : 2.5f;
     for (int j = 0; j < 7; j++) {
         a.out[j] = d_out[j];
         if (a.out[j] && ((uintptr_t)a.out[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: output plane unaligned");

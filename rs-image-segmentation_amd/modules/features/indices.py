@@ -43,7 +43,7 @@ def robust_normalize(band, lower_percentile=2, upper_percentile=98):
     return _host(_ctx().normalize(d, float(lo), float(hi)), shape)
 
 
-def _indices(nir=None, red=None, blue=None, green=None, swir=None, which=0):
+def _indices(nir=None, red=None, blue=None, green=None, swir=None, which=0, evi_coef=None):
     ref = next(x for x in (nir, red, blue, green, swir) if x is not None)
     shape = np.asarray(ref).shape
     zeros = None
@@ -56,7 +56,7 @@ def _indices(nir=None, red=None, blue=None, green=None, swir=None, which=0):
         else:
             planes.append(_dev(b)[0])
     want = [i == which for i in range(7)]
-    outs, _ = _ctx().spectral_indices(planes, None, want=want)
+    outs, _ = _ctx().spectral_indices(planes, None, want=want, evi_coef=evi_coef)
     return _host(outs[which], shape)
 
 
@@ -65,9 +65,7 @@ def calculate_ndvi(nir_band, red_band):  # indices.py:50-71
 
 
 def calculate_evi(nir_band, red_band, blue_band, L=1, C1=6, C2=7.5, G=2.5):  # indices.py:73-95
-    if (L, C1, C2, G) != (1, 6, 7.5, 2.5):
-        raise ValueError("calculate_evi: only the reference's default coefficients (L=1, C1=6, C2=7.5, G=2.5) are compiled in")
-    return _indices(nir=nir_band, red=red_band, blue=blue_band, which=1)
+    return _indices(nir=nir_band, red=red_band, blue=blue_band, which=1, evi_coef=(L, C1, C2, G))
 
 
 def calculate_msavi(nir_band, red_band):  # indices.py:97-114
@@ -103,11 +101,29 @@ def perform_pca(bands_data, n_components=None, use_robust_scaling=True):
     fitted model exposing components_/mean_/explained_variance_/explained_variance_ratio_/transform)."""
     if len(bands_data) < 1:
         raise ValueError("perform_pca: bands_data is empty")
-    if not use_robust_scaling:
-        raise ValueError("perform_pca: only use_robust_scaling=True (the reference's only call site) is implemented")
     shape = np.asarray(bands_data[0]).shape
     planes = [_dev(b)[0] for b in bands_data]
-    outs, ratio, m = _P.pca(_ctx(), planes, n_components, True)
+    ctx = _ctx()
+    n = int(np.prod(shape))
+    nans = 0
+    if use_robust_scaling:
+        from rsseg.quantiles import robust_scaler_stats
+        stats = []
+        for p in planes:   # RobustScaler ignores NaNs (nanmedian / nanpercentile); PCA then refuses them, as sklearn does
+            stats.append(robust_scaler_stats(ctx, p))
+        outs, ratio, m = _P.pca(ctx, planes, n_components, True, stats=stats)
+    else:
+        # (X - min) / (max - min + 1e-10) in float32 (indices.py:232-234): the arithmetic of robust_normalize with the
+        # extrema in place of the percentiles, applied inside the PCA kernels
+        lohi = np.zeros((len(planes), 2), np.float32)
+        for i, p in enumerate(planes):
+            vals, nn = ctx.order_stats(p, [0, max(n - 1, 0)])
+            nans += nn
+            lohi[i] = vals
+        if nans:
+            raise ValueError("Input X contains NaN.")
+        outs, comp, ratio, mean, ev = ctx.pca_fit_transform(planes, None, None, len(planes) if n_components is None else n_components, lohi)
+        m = dict(components=comp, mean=mean, explained_variance=ev, center=None, scale=None)
     result = [_host(o, shape) for o in outs]
     try:
         from sklearn.decomposition import PCA

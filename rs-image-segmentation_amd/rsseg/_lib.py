@@ -17,6 +17,7 @@ F32, F64, I64 = 0, 1, 2
 SUM, MIN, MAX = 0, 1, 2
 BORDER_REFLECT, BORDER_REFLECT101 = 0, 1
 MORPH_ERODE, MORPH_DILATE, MORPH_OPEN, MORPH_CLOSE, MORPH_GRADIENT = 0, 1, 2, 3, 4
+MASK_AND, MASK_OR, MASK_ANDNOT, MASK_NOT = 0, 1, 2, 3
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int)
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rsseg_order_stats_multi_f32": (_int, [_vp, C.POINTER(_vp), _int, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
     "rsseg_normalize_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
     "rsseg_spectral_indices_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP]),
+    "rsseg_spectral_indices_evi_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP, C.POINTER(C.c_float)]),
     "rsseg_pca_fit_transform_f32": (_int, [_vp, _PP, _int, _i64, C.POINTER(C.c_float), C.POINTER(C.c_double), _int, _PP,
                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                            C.POINTER(C.c_float)]),
@@ -93,6 +95,13 @@ SIGNATURES = {
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8),
                                  C.POINTER(C.c_double), _int, C.POINTER(_i64), _int]),
     "rsseg_forest_predict": (_int, [_vp, _PP, _int, _i64, _vp]),
+    "rsseg_threshold_band_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
+    "rsseg_mask_op_u8": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "rsseg_mask_paint_u8": (_int, [_vp, _vp, _vp, _i64, _int, _int]),
+    "rsseg_morph_ellipse_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "rsseg_remove_small_components_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_host_lzw_encode": (_i64, [_vp, _i64, _vp, _i64]),
+    "rsseg_host_lzw_decode": (_i64, [_vp, _i64, _vp, _i64]),
     "rsseg_host_kmeans_draws": (_int, [C.c_uint32, _i64, _int, _int, C.POINTER(_i64), C.POINTER(C.c_double)]),
 }
 

@@ -131,22 +131,33 @@ def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size
 
 
 def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=21, glcm_step=21, glcm_levels=32,
-                    n_global: Optional[int] = None):
+                    n_global: Optional[int] = None, preprocessing: bool = True):
     """The 19 planes of hierarchical_features['all'] (scripts/2:112-127), in stack order.
     Returns (planes, dtypes_note): all planes float32 except index 16 (gradient_5) which is uint8 on
-    the device and becomes uint8/255.0 (float64) on the host, as in indices.py:440."""
-    qb = band_quantile_bundles(ctx, bands, n_global)
-    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
-    idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
-    norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
-    fused = all(q["center"] is not None for q in qb)
-    pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
+    the device and becomes uint8/255.0 (float64) on the host, as in indices.py:440.
+    preprocessing=False (scripts/2:39-47): the bands are used as given — indices and PCA on the caller's values; the
+    texture functions still robust-normalise the band they receive (indices.py:265, 412, 455, 531)."""
+    if not preprocessing:
+        idx, _ = spectral_indices(ctx, bands, None)
+        norm_all = list(bands)
+        pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, None)
+        nir2 = renormalize(ctx, bands[3], n_global)
+        lohi, fused, qb = None, False, None
+    else:
+        qb = band_quantile_bundles(ctx, bands, n_global)
+        lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+        idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+        norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+        fused = all(q["center"] is not None for q in qb)
+        pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
+        nir2 = None
     level1 = [idx["ndwi"], idx["mndwi"], idx["ndvi"], idx["evi"], idx["ndbi"], idx["bsi"], pcs[0]]
     ctx_planes = ctx.box_mean_multi(level1, H, W, 7, L.BORDER_REFLECT)   # the 7 channels of add_spatial_context in one launch
-    if fused:
-        nir2 = ctx.normalize(norm_all[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]))
-    else:
-        nir2 = renormalize(ctx, norm_all[3], n_global)
+    if nir2 is None:
+        if fused:
+            nir2 = ctx.normalize(norm_all[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]))
+        else:
+            nir2 = renormalize(ctx, norm_all[3], n_global)
     glcm, _ = glcm_features(ctx, nir2, H, W, glcm_levels, glcm_window, glcm_step)
     q255 = ctx.quantize_u8(nir2, 255.0)
     grad = ctx.morph_gradient(q255, H, W, 5)

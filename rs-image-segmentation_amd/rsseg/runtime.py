@@ -228,7 +228,7 @@ class Context:
         return out
 
     def spectral_indices(self, bands5: Sequence, lohi: Optional[np.ndarray], want_norm: Sequence[bool] = (False,) * 5,
-                         want: Sequence[bool] = (True,) * 7):
+                         want: Sequence[bool] = (True,) * 7, evi_coef: Optional[Sequence[float]] = None):
         torch = _torch()
         n = bands5[0].numel()
         outs = [self.empty(n, torch.float32) if w else None for w in want]
@@ -236,7 +236,8 @@ class Context:
         lh = None
         if lohi is not None:
             lh = (C.c_float * 10)(*[float(v) for v in np.asarray(lohi, np.float32).reshape(-1)])
-        self._chk(self.lib.rsseg_spectral_indices_f32(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms)))
+        ec = None if evi_coef is None else (C.c_float * 4)(*[float(np.float32(v)) for v in evi_coef])   # {L, C1, C2, G}
+        self._chk(self.lib.rsseg_spectral_indices_evi_f32(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms), ec))
         self._tag_minmax(outs)
         return outs, norms
 
@@ -377,6 +378,39 @@ class Context:
         y0, y1 = self._rows(H, rows)
         out = self.empty((y1 - y0) * W, torch.float32)
         self._chk(self.lib.rsseg_sobel_mag_rows_u8(self.h, C.c_void_p(q.data_ptr()), H, W, y0, y1, edges, C.c_void_p(out.data_ptr())))
+        return out
+
+    # ---- K12: rule-based classification -------------------------------------------------------
+    def threshold_band(self, plane, lo: float = float("-inf"), hi: float = float("inf")):
+        """uint8 mask: 1 where lo < x < hi (NaN counts as 0)."""
+        torch = _torch()
+        out = self.empty(plane.numel(), torch.uint8)
+        self._chk(self.lib.rsseg_threshold_band_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo), C.c_float(hi),
+                                                    C.c_void_p(out.data_ptr())))
+        return out
+
+    def mask_op(self, a, b, op: int):
+        torch = _torch()
+        out = self.empty(a.numel(), torch.uint8)
+        self._chk(self.lib.rsseg_mask_op_u8(self.h, C.c_void_p(a.data_ptr()), None if b is None else C.c_void_p(b.data_ptr()), a.numel(), op,
+                                            C.c_void_p(out.data_ptr())))
+        return out
+
+    def mask_paint(self, final_map, mask, value: int, only_unset: bool = False):
+        self._chk(self.lib.rsseg_mask_paint_u8(self.h, C.c_void_p(final_map.data_ptr()), C.c_void_p(mask.data_ptr()), final_map.numel(), value,
+                                               int(only_unset)))
+        return final_map
+
+    def morph_ellipse(self, q, H: int, W: int, k: int, op: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_morph_ellipse_u8(self.h, C.c_void_p(q.data_ptr()), H, W, k, op, C.c_void_p(out.data_ptr())))
+        return out
+
+    def remove_small_components(self, mask, H: int, W: int, min_area: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_remove_small_components_u8(self.h, C.c_void_p(mask.data_ptr()), H, W, int(min_area), C.c_void_p(out.data_ptr())))
         return out
 
     # ---- K9/K10 --------------------------------------------------------------------------------

