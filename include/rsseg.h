@@ -277,6 +277,19 @@ int rsseg_morph_ellipse_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int
  * stripes, so this operator is not row-sharded). */
 int rsseg_remove_small_components_u8(rsseg_ctx *ctx, const uint8_t *d_mask, int H, int W, int min_area, uint8_t *d_out);
 
+/* ---- K13: remaining texture members of the feature dictionary ---------------- */
+/* calculate_lbp_features (indices.py:320-344): skimage.feature.local_binary_pattern(u8, n_points, radius, 'uniform');
+ * d_out: the codes 0 .. n_points + 1 as uint8 (the caller divides by their maximum in float64, :342). */
+int rsseg_lbp_uniform_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int n_points, double radius, uint8_t *d_out);
+/* entropy_scale_k (indices.py:551-560): skimage.filters.rank.entropy(u8, disk(radius)), float64, radius in {1,2,3,5,7}
+ * (the caller divides by the maximum, :559). */
+int rsseg_rank_entropy_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int radius, double *d_out);
+/* gaussian_5 / gaussian_15 (indices.py:463-464): cv2.GaussianBlur(u8, (ksize, ksize), 0), OpenCV's fixed-point path for
+ * 8-bit images, BORDER_REFLECT_101; uint8 out (the caller divides by 255.0 and forms the DoG, :463-470). */
+int rsseg_gaussian_blur_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int ksize, uint8_t *d_out);
+/* host-only: the ksize taps of that blur in 8 fractional bits (they sum to 256). */
+int rsseg_host_gaussian_kernel_fixed(int ksize, int *taps);
+
 /* ---- host-only helper (no GPU needed) ------------------------------------------------------- */
 /* The random draws of k-means++ as the library makes them (numpy RandomState(seed): MT19937, random_sample,
  * RandomState.choice over n equal weights — sklearn/cluster/_kmeans.py:213-270): *center_id = index of the first

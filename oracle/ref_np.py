@@ -443,6 +443,110 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
 
 
 # --------------------------------------------------------------------------------------------
+# LBP, rank entropy, fixed-point Gaussian (indices.py:320-344, 551-560, 463-470) — scikit-image / OpenCV semantics restated
+# from their published algorithms (libraries absent, unpinned in the reference: parity unpinned)
+# --------------------------------------------------------------------------------------------
+def lbp_uniform(u8: np.ndarray, P: int = 24, R: float = 3) -> np.ndarray:
+    """skimage.feature.local_binary_pattern(u8, P, R, method='uniform') (texture.py + _texture.pyx):
+    float64 image, offsets np.round(+-R sin/cos(2 pi i / P), 5), bilinear interpolation with constant 0 outside,
+    s_i = sample - centre >= 0, changes over the P - 1 consecutive pairs, code = sum s_i if changes <= 2 else P + 1."""
+    img = u8.astype(np.float64)
+    H, W = img.shape
+    rp = np.round(-R * np.sin(2 * np.pi * np.arange(P, dtype=np.float64) / P), 5)
+    cp = np.round(R * np.cos(2 * np.pi * np.arange(P, dtype=np.float64) / P), 5)
+    rr, cc = np.mgrid[0:H, 0:W].astype(np.float64)
+
+    def px(r, c):
+        ok = (r >= 0) & (r < H) & (c >= 0) & (c < W)
+        out = np.zeros(r.shape, np.float64)
+        out[ok] = img[r[ok], c[ok]]
+        return out
+
+    s = np.zeros((P, H, W), np.int8)
+    for i in range(P):
+        r, c = rr + rp[i], cc + cp[i]
+        minr, minc = np.floor(r).astype(np.int64), np.floor(c).astype(np.int64)
+        maxr, maxc = np.ceil(r).astype(np.int64), np.ceil(c).astype(np.int64)
+        dr, dc = r - minr, c - minc
+        top = (1 - dc) * px(minr, minc) + dc * px(minr, maxc)
+        bottom = (1 - dc) * px(maxr, minc) + dc * px(maxr, maxc)
+        s[i] = ((1 - dr) * top + dr * bottom) - img >= 0
+    changes = (s[:-1] != s[1:]).sum(0)
+    return np.where(changes <= 2, s.sum(0), P + 1).astype(np.float64)
+
+
+def disk(radius: int) -> np.ndarray:
+    """skimage.morphology.disk"""
+    L = np.arange(-radius, radius + 1)
+    X, Y = np.meshgrid(L, L)
+    return (X ** 2 + Y ** 2 <= radius ** 2).astype(np.uint8)
+
+
+def rank_entropy(u8: np.ndarray, radius: int) -> np.ndarray:
+    """skimage.filters.rank.entropy(u8, disk(radius)) (rank/generic_cy.pyx::_kernel_entropy): local histogram over the
+    in-image part of the footprint, e = - sum_i p_i log(p_i) / ln 2 over the bins in ascending order, float64."""
+    H, W = u8.shape
+    fp = disk(radius)
+    out = np.zeros((H, W), np.float64)
+    offs = [(dy - radius, dx - radius) for dy in range(2 * radius + 1) for dx in range(2 * radius + 1) if fp[dy, dx]]
+    for r in range(H):
+        for c in range(W):
+            vals = [u8[r + dy, c + dx] for dy, dx in offs if 0 <= r + dy < H and 0 <= c + dx < W]
+            cnt = np.bincount(vals, minlength=256)
+            e = 0.0
+            pop = float(len(vals))
+            for i in np.nonzero(cnt)[0]:
+                p = cnt[i] / pop
+                e -= p * math.log(p) / 0.6931471805599453
+            out[r, c] = e
+    return out
+
+
+def gaussian_taps_fixed(ksize: int) -> np.ndarray:
+    """OpenCV's 8-bit fixed-point Gaussian taps for sigma = 0 (imgproc/src/smooth.dispatch.cpp: getGaussianKernel +
+    getGaussianKernelFixedPoint_ED): the small fixed tables up to 7 taps, else exp(-x^2 / 2 sigma^2) with
+    sigma = 0.3 ((k - 1) / 2 - 1) + 0.8, normalised; rounded half-to-even with error diffusion, centre = 256 - rest."""
+    small = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if ksize in small:
+        k = np.array(small[ksize], np.float64)
+    else:
+        sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
+        x = np.arange(ksize) - (ksize - 1) * 0.5
+        k = np.exp(-0.5 / (sigma * sigma) * x * x)
+        k = k * (1.0 / k.sum())
+    taps = np.zeros(ksize, np.int64)
+    err = 0.0
+    for i in range(ksize // 2):
+        adj = k[i] * 256.0 + err
+        v0 = int(np.rint(adj))
+        err = adj - v0
+        taps[i] = taps[ksize - 1 - i] = v0
+    taps[ksize // 2] = 256 - 2 * taps[:ksize // 2].sum()
+    return taps
+
+
+def gaussian_blur_u8(u8: np.ndarray, ksize: int) -> np.ndarray:
+    """cv2.GaussianBlur(u8, (k, k), 0): rows in 8.8 fixed point, columns in 16.16, (acc + 2^15) >> 16, BORDER_REFLECT_101."""
+    taps = gaussian_taps_fixed(ksize)
+    r = ksize // 2
+    p = np.pad(u8.astype(np.int64), r, mode="reflect")
+    H, W = u8.shape
+    hor = sum(p[:, t:t + W] * taps[t] for t in range(ksize))             # (H + 2r, W), at most 255 * 256
+    acc = sum(hor[t:t + H] * taps[t] for t in range(ksize))
+    return np.minimum((acc + 32768) >> 16, 255).astype(np.uint8)
+
+
+def filter_responses_extra(band: np.ndarray) -> dict:
+    """calculate_filter_responses' gaussian_5, gaussian_15, dog (indices.py:463-470)."""
+    u8 = to_u8(robust_normalize(band))
+    g5 = gaussian_blur_u8(u8, 5) / 255.0
+    g15 = gaussian_blur_u8(u8, 15) / 255.0
+    dog = g5 - g15
+    return {"gaussian_5": g5, "gaussian_15": g15, "dog": (dog - dog.min()) / (dog.max() - dog.min() + 1e-10)}
+
+
+# --------------------------------------------------------------------------------------------
 # rule-based classification   (modules/features/extract.py:299-505; scripts/3_classification.py:335-375)
 # scipy.ndimage.label is the reference's own dependency and is installed: the component filter below CALLS it, so
 # that part of the oracle is the real library.  cv2.morphologyEx with cv2.getStructuringElement(MORPH_ELLIPSE) is

@@ -440,7 +440,6 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
         trees[t].n_nodes = cnt;
         trees[t].leaf_off = 0;
         trees[t].pad = 0;
-        int nleaf = 0;
         for (int h = 0; h < cnt; h++) {
             const int64_t g = b + order[h];
             rf_node &nd = nodes[(size_t)(b + h)];
@@ -458,7 +457,6 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
                     const size_t row = leaf.size() / NCP;
                     if (row > RF_PAY_MASK) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "forest_load: more than %u mixed leaves in the forest", RF_PAY_MASK);
                     pay = (unsigned)row;
-                    nleaf++;
                     for (int c = 0; c < NCP; c++) leaf.push_back(c < n_classes ? v[c] : 0.0);
                 }
                 const unsigned tb = RF_NAN_BITS | pay;   // the vote rides in the payload of a NaN threshold

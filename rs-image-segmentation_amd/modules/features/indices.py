@@ -4,9 +4,8 @@ names, positional order, defaults, NumPy-in / NumPy-out contract and dtypes (SUR
 the arithmetic done by the gfx950 kernels of librsseg_hip.so.  Inputs are never modified; outputs are
 fresh host arrays.  There is no CPU fallback: without the HIP library / an MI355X these raise.
 
-Functions of the reference module that are plotting or never reach the classifier (visualize_*,
-LBP, Gabor, entropy, erosion/dilation/opening/closing, gaussian/DoG/laplacian) are out of scope
-(§8f N3).
+Functions of the reference module that are plotting (visualize_*) or never called by the stages (Gabor, HOG, ...)
+are out of scope; every member of the stage-2 feature dictionary is produced.
 """
 from __future__ import annotations
 
@@ -19,7 +18,7 @@ from rsseg.runtime import default_context as _ctx
 
 __all__ = [
     "robust_normalize", "calculate_ndvi", "calculate_evi", "calculate_msavi", "calculate_ndwi", "calculate_mndwi",
-    "calculate_ndbi", "calculate_bsi", "perform_pca", "calculate_glcm_features", "calculate_morphological_features",
+    "calculate_ndbi", "calculate_bsi", "perform_pca", "calculate_glcm_features", "calculate_lbp_features", "calculate_morphological_features",
     "calculate_multi_scale_features", "calculate_filter_responses", "add_spatial_context", "prepare_level_1_features",
     "prepare_level_2_features", "np",
 ]
@@ -155,6 +154,15 @@ def calculate_glcm_features(band, distances=[1], angles=[0, np.pi / 4, np.pi / 2
     return {k: _host(v, (h, w)) for k, v in feats.items()}
 
 
+def calculate_lbp_features(band, radius=3, n_points=24):
+    """reference indices.py:320-344: uniform LBP codes of the re-normalised uint8 band, divided by their maximum (float64)."""
+    d, (h, w) = _dev(band)
+    ctx = _ctx()
+    q = ctx.quantize_u8(_P.renormalize(ctx, d), 255.0)
+    lbp = _host(ctx.lbp_uniform(q, h, w, n_points, radius), (h, w)).astype(np.float64)
+    return lbp / lbp.max()
+
+
 def calculate_morphological_features(band):
     """reference indices.py:401-442 — erosion / dilation / opening / closing / gradient at 3, 5, 7 (float64, u8 / 255.0;
     the stack consumes 'gradient_5')."""
@@ -167,31 +175,43 @@ def calculate_morphological_features(band):
 
 
 def calculate_multi_scale_features(band, scales=[1, 3, 5, 7]):
-    """reference indices.py:519-562 — mean_scale_k, variance_scale_k and std_dev_scale_k (the stack consumes
-    'std_dev_scale_5'); the rank-filter entropy members (scikit-image) are not produced."""
+    """reference indices.py:519-562 — mean_scale_k, variance_scale_k, std_dev_scale_k (the stack consumes
+    'std_dev_scale_5') and, for scales <= 5, entropy_scale_k (rank entropy over disk(k), divided by its maximum)."""
     d, (h, w) = _dev(band)
     ctx = _ctx()
     n = _P.renormalize(ctx, d)
+    q = ctx.quantize_u8(n, 255.0)
     out = {}
     for k in scales:
         if k == 1:  # a 1x1 blur is the identity: variance = x*x - x*x = 0
             out["mean_scale_1"] = _host(n, (h, w))
             out["variance_scale_1"] = np.zeros((h, w), np.float32)
             out["std_dev_scale_1"] = np.zeros((h, w), np.float32)
-            continue
-        out[f"mean_scale_{k}"] = _host(ctx.box_mean(n, h, w, k, _L.BORDER_REFLECT101), (h, w))
-        out[f"variance_scale_{k}"] = _host(ctx.local_var(n, h, w, k), (h, w))
-        out[f"std_dev_scale_{k}"] = _host(ctx.local_std(n, h, w, k), (h, w))
+        else:
+            out[f"mean_scale_{k}"] = _host(ctx.box_mean(n, h, w, k, _L.BORDER_REFLECT101), (h, w))
+            out[f"variance_scale_{k}"] = _host(ctx.local_var(n, h, w, k), (h, w))
+            out[f"std_dev_scale_{k}"] = _host(ctx.local_std(n, h, w, k), (h, w))
+        if k <= 5:
+            e = _host(ctx.rank_entropy(q, h, w, k), (h, w))
+            out[f"entropy_scale_{k}"] = e / np.max(e)
     return out
 
 
 def calculate_filter_responses(band):
-    """reference indices.py:444-482 — 'laplacian' and 'sobel_mag' (the member the stack consumes); the Gaussian /
-    DoG members (cv2's fixed-point uint8 GaussianBlur) are not produced."""
+    """reference indices.py:444-482 — gaussian_5, gaussian_15 (uint8 blur / 255.0, float64), dog (their difference,
+    min-max normalised), laplacian, sobel_mag (the member the stack consumes)."""
     d, (h, w) = _dev(band)
     ctx = _ctx()
     q = ctx.quantize_u8(_P.renormalize(ctx, d), 255.0)
-    return {"laplacian": _host(ctx.laplacian_norm(q, h, w), (h, w)), "sobel_mag": _host(ctx.sobel_mag(q, h, w), (h, w))}
+    return filter_members(ctx, q, h, w)
+
+
+def filter_members(ctx, q, h, w):
+    g5 = _host(ctx.gaussian_blur_u8(q, h, w, 5), (h, w)) / 255.0
+    g15 = _host(ctx.gaussian_blur_u8(q, h, w, 15), (h, w)) / 255.0
+    dog = g5 - g15
+    return {"gaussian_5": g5, "gaussian_15": g15, "dog": (dog - dog.min()) / (dog.max() - dog.min() + 1e-10),
+            "laplacian": _host(ctx.laplacian_norm(q, h, w), (h, w)), "sobel_mag": _host(ctx.sobel_mag(q, h, w), (h, w))}
 
 
 def add_spatial_context(features_array, window_size=7):

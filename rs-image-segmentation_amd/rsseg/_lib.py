@@ -100,6 +100,10 @@ SIGNATURES = {
     "rsseg_mask_paint_u8": (_int, [_vp, _vp, _vp, _i64, _int, _int]),
     "rsseg_morph_ellipse_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "rsseg_remove_small_components_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_lbp_uniform_u8": (_int, [_vp, _vp, _int, _int, _int, C.c_double, _vp]),
+    "rsseg_rank_entropy_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_gaussian_blur_u8": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "rsseg_host_gaussian_kernel_fixed": (_int, [_int, C.POINTER(_int)]),
     "rsseg_host_lzw_encode": (_i64, [_vp, _i64, _vp, _i64]),
     "rsseg_host_lzw_decode": (_i64, [_vp, _i64, _vp, _i64]),
     "rsseg_host_kmeans_draws": (_int, [C.c_uint32, _i64, _int, _int, C.POINTER(_i64), C.POINTER(C.c_double)]),

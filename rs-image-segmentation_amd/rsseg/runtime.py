@@ -380,6 +380,25 @@ class Context:
         self._chk(self.lib.rsseg_sobel_mag_rows_u8(self.h, C.c_void_p(q.data_ptr()), H, W, y0, y1, edges, C.c_void_p(out.data_ptr())))
         return out
 
+    # ---- K13: LBP, rank entropy, fixed-point Gaussian ---------------------------------------------
+    def lbp_uniform(self, q, H: int, W: int, n_points: int = 24, radius: float = 3):
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_lbp_uniform_u8(self.h, C.c_void_p(q.data_ptr()), H, W, n_points, C.c_double(radius), C.c_void_p(out.data_ptr())))
+        return out
+
+    def rank_entropy(self, q, H: int, W: int, radius: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.float64)
+        self._chk(self.lib.rsseg_rank_entropy_u8(self.h, C.c_void_p(q.data_ptr()), H, W, radius, C.c_void_p(out.data_ptr())))
+        return out
+
+    def gaussian_blur_u8(self, q, H: int, W: int, ksize: int):
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_gaussian_blur_u8(self.h, C.c_void_p(q.data_ptr()), H, W, ksize, C.c_void_p(out.data_ptr())))
+        return out
+
     # ---- K12: rule-based classification -------------------------------------------------------
     def threshold_band(self, plane, lo: float = float("-inf"), hi: float = float("inf")):
         """uint8 mask: 1 where lo < x < hi (NaN counts as 0)."""

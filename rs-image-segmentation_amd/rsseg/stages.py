@@ -38,8 +38,7 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     fd["pca_result"] = [host(p) for p in ex["pca"]]
     fd["variance_ratio"] = ex["pca_ratio"]
     fd["glcm_features"] = {k: host(v) for k, v in ex["glcm"].items()}
-    # the window-operator members of the dict (indices.py:401-482, 519-562) beyond the three the stack consumes;
-    # not produced: LBP, rank-filter entropy (scikit-image), Gaussian / DoG (cv2 fixed-point GaussianBlur)
+    # the window-operator members of the dict (indices.py:320-344, 401-482, 519-562) beyond the three the stack consumes
     from . import _lib as L
     nir2, q255 = ex["nir2"], ex["q255"]  # the re-normalised NIR band and its uint8 image (indices.py:412-415)
     ops = (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE),
@@ -51,8 +50,17 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
         ms[f"mean_scale_{k}"] = host(ctx.box_mean(nir2, h, w, k, L.BORDER_REFLECT101))
         ms[f"variance_scale_{k}"] = host(ctx.local_var(nir2, h, w, k))
         ms[f"std_dev_scale_{k}"] = host(planes[17]) if k == 5 else host(ctx.local_std(nir2, h, w, k))
+    for k in (1, 3, 5):
+        e = ctx.rank_entropy(q255, h, w, k).cpu().numpy().reshape(h, w)
+        ms[f"entropy_scale_{k}"] = e / np.max(e)
     fd["multi_scale_features"] = ms
-    fd["filter_features"] = {"laplacian": host(ctx.laplacian_norm(q255, h, w)), "sobel_mag": host(planes[18])}
+    lbp = ctx.lbp_uniform(q255, h, w, 24, 3).cpu().numpy().reshape(h, w).astype(np.float64)
+    fd["lbp_feature"] = lbp / lbp.max()
+    g5 = ctx.gaussian_blur_u8(q255, h, w, 5).cpu().numpy().reshape(h, w) / 255.0
+    g15 = ctx.gaussian_blur_u8(q255, h, w, 15).cpu().numpy().reshape(h, w) / 255.0
+    dog = g5 - g15
+    fd["filter_features"] = {"gaussian_5": g5, "gaussian_15": g15, "dog": (dog - dog.min()) / (dog.max() - dog.min() + 1e-10),
+                             "laplacian": host(ctx.laplacian_norm(q255, h, w)), "sobel_mag": host(planes[18])}
     stack = P.stack19_to_host(planes, h, w)
     hier = {"level_1": np.ascontiguousarray(stack[:, :, :14]), "level_2": np.ascontiguousarray(stack[:, :, 14:]), "all": stack}
     return fd, hier

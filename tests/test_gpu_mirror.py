@@ -48,7 +48,7 @@ def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
     for k in want:
         assert mf[k].dtype == np.float64 and np.array_equal(mf[k], want[k]), k
     ms = I.calculate_multi_scale_features(nir)
-    assert {f"{m}_scale_{k}" for m in ("mean", "variance", "std_dev") for k in (1, 3, 5, 7)} == set(ms)
+    assert ({f"{m}_scale_{k}" for m in ("mean", "variance", "std_dev") for k in (1, 3, 5, 7)} | {f"entropy_scale_{k}" for k in (1, 3, 5)}) == set(ms)
     assert np.array_equal(ms["std_dev_scale_5"], oracle.std_dev_feature(nir, 5))
     assert np.array_equal(ms["variance_scale_3"], oracle.variance_feature(nir, 3))
     assert not ms["variance_scale_1"].any() and ms["variance_scale_1"].dtype == np.float32
@@ -68,11 +68,15 @@ def test_stage_function_layout_and_files(ctx, crop, tmp_path, oracle):
         tol = 2e-4 if c in (6, 13) else 1e-5
         assert np.allclose(hier["all"][:, :, c], want["all"][:, :, c], rtol=0, atol=tol), c
     # the dict members around the stack (indices.py:401-482, 519-562)
-    assert len(fd["morphological_features"]) == 15 and len(fd["multi_scale_features"]) == 12
+    assert len(fd["morphological_features"]) == 15 and len(fd["multi_scale_features"]) == 15   # + entropy_scale_1 / 3 / 5
     assert np.array_equal(fd["morphological_features"]["gradient_5"], hier["all"][:, :, 16])
     assert np.array_equal(fd["multi_scale_features"]["std_dev_scale_5"].astype(np.float64), hier["all"][:, :, 17])
     assert np.array_equal(fd["morphological_features"]["closing_7"], oracle.calculate_morphological_features(crop["norm"][3])["closing_7"])
-    assert set(fd["filter_features"]) == {"laplacian", "sobel_mag"}
+    assert set(fd["filter_features"]) == {"gaussian_5", "gaussian_15", "dog", "laplacian", "sobel_mag"}
+    # every key scripts/2:62-106 puts into features_dict
+    assert set(fd) == {"ndvi", "evi", "msavi", "ndwi", "mndwi", "ndbi", "bsi", "pca_result", "variance_ratio", "glcm_features", "lbp_feature",
+                       "multi_scale_features", "morphological_features", "filter_features"}
+    assert fd["lbp_feature"].dtype == np.float64 and fd["lbp_feature"].max() == 1.0
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
     assert np.array_equal(np.load(paths["all"]), hier["all"])
     import pickle
@@ -294,3 +298,44 @@ def test_rule_based_classification_vs_oracle(ctx, scene, oracle, tmp_path):
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 600, 600)
     out = stages.run_classification_stage(paths["pkl"], "rule_based", str(tmp_path / "cls"))
     assert np.array_equal(out, want)
+
+
+def test_lbp_entropy_gaussian_members_vs_oracle(ctx, crop, oracle):
+    """SURVEY.md 8f N3, the last members of the stage-2 dictionary: uniform LBP (bit-exact codes), rank entropy over
+    disk(1 / 3 / 5) (float64, 1e-12: the device log is not glibc's), OpenCV's fixed-point Gaussian 5 / 15 (bit-exact
+    uint8) and the DoG — against the NumPy restatements, on an odd-sized plane and through the mirror functions."""
+    from modules.features import indices as I
+    from rsseg import _lib as L
+    import ctypes as C
+    rng = np.random.default_rng(33)
+    H, W = 53, 71
+    q = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    q[10:30, 20:50] = (np.add.outer(np.arange(20), np.arange(30)) * 3 % 256).astype(np.uint8)   # smooth ramp: many exact ties
+    q[35:45, 5:25] = 200
+    d = ctx.to_device(q.reshape(-1))
+    for P, R in ((24, 3), (8, 1), (16, 2)):
+        got = ctx.lbp_uniform(d, H, W, P, R).cpu().numpy().reshape(H, W)
+        assert np.array_equal(got.astype(np.float64), oracle.lbp_uniform(q, P, R)), (P, R)
+    for k in (1, 3, 5):
+        got = ctx.rank_entropy(d, H, W, k).cpu().numpy().reshape(H, W)
+        assert np.allclose(got, oracle.rank_entropy(q, k), rtol=0, atol=1e-12), k
+    for ks in (5, 15, 3, 7, 9):
+        taps = (C.c_int * ks)()
+        assert L.load().rsseg_host_gaussian_kernel_fixed(ks, taps) == 0
+        assert list(taps) == list(oracle.gaussian_taps_fixed(ks)) and sum(taps) == 256, ks
+        assert np.array_equal(ctx.gaussian_blur_u8(d, H, W, ks).cpu().numpy().reshape(H, W), oracle.gaussian_blur_u8(q, ks)), ks
+    assert list(oracle.gaussian_taps_fixed(5)) == [16, 64, 96, 64, 16]
+    band = crop["bands"][3]
+    f = I.calculate_filter_responses(band)
+    want = oracle.filter_responses_extra(band)
+    for k in ("gaussian_5", "gaussian_15", "dog"):
+        assert f[k].dtype == np.float64 and np.array_equal(f[k], want[k]), k
+    assert set(f) == {"gaussian_5", "gaussian_15", "dog", "laplacian", "sobel_mag"}
+    u8 = oracle.to_u8(oracle.robust_normalize(band))
+    lbp = I.calculate_lbp_features(band)
+    o = oracle.lbp_uniform(u8, 24, 3)
+    assert lbp.dtype == np.float64 and np.array_equal(lbp, o / o.max())
+    ms = I.calculate_multi_scale_features(band)
+    assert {"entropy_scale_1", "entropy_scale_3", "entropy_scale_5"} <= set(ms) and "entropy_scale_7" not in ms
+    e3 = oracle.rank_entropy(u8, 3)
+    assert np.allclose(ms["entropy_scale_3"], e3 / e3.max(), rtol=0, atol=1e-12)
