@@ -66,7 +66,7 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
 def family_table(cfg, F, glcm_step, k, n_pca):
     """kernel family -> (bound, algorithmic HBM bytes per pixel and launch) — SURVEY.md §8(d), DESIGN.md §5.
     'lloyd' is charged the bytes it moves (F float32 planes + uint8 label read + write), not int32 labels."""
-    idx_out = 7 * 4 + (4 if cfg == "c3" else (20 if cfg == "c5" else 0))   # + the normalised bands the config keeps
+    idx_out = 7 * 4 + (4 if cfg in ("c3", "c5") else 0)   # + the normalised NIR band the texture chain reads
     return {
         "kpp": ("hbm", (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1)),   # k passes: F planes in, closest plane r/w from round 2 on
         "lloyd": ("hbm", 4 * F + 2),
@@ -305,6 +305,8 @@ def main():
                    "hbm_GBs": round(px * bpp / per_launch_s / 1e9, 1), "hbm_frac": round(px * bpp / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)}
             if bound == "hbm":
                 ent["frac"] = ent["hbm_frac"]
+            elif bound == "valu" and cfg != "c3":
+                ent["frac"] = None      # window 21 / step 21 runs the workgroup-per-window kernel: no instruction model for it
             elif bound == "valu":
                 cyc = glcm_issue_cycles()
                 waves = px / 64.0

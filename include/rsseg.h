@@ -176,6 +176,11 @@ int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw
 int rsseg_resize_bilinear_rows_f32(rsseg_ctx *ctx, const float *d_src, int sh_local, int sw, int src_row0, int sh,
                                    float *d_dst, int dh_local, int dw, int dst_row0, int dh);
 
+/* The same for nplanes (<= 8) source maps of one shape in ONE launch (the five GLCM property maps, indices.py:307-310);
+ * with rsseg_ctx_collect_minmax on, rsseg_ctx_last_minmax(plane) returns the extrema of each. */
+int rsseg_resize_bilinear_rows_multi_f32(rsseg_ctx *ctx, const float *const *d_src, int nplanes, int sh_local, int sw, int src_row0, int sh,
+                                         float *const *d_dst, int dh_local, int dw, int dst_row0, int dh);
+
 /* ---- K6/K7/K8: window operators ---------------------------------------------------------- */
 /* Every operator exists in a ROWS form for row-sharded rasters: the plane holds Hin rows, rows
  * [y0, y1) are produced into a compact (y1 - y0) x W output.  edges bit 0 / bit 1 say that row 0 / row Hin - 1 is the

@@ -55,11 +55,12 @@ struct rsseg_ctx {
     forest_dev forest;
     // optional per-plane extrema of the planes the last producing call wrote (rsseg_ctx_collect_minmax)
     bool mm_collect = false;
-    uint32_t *d_mm = nullptr;  // [RSSEG_MM_PLANES][2] ordered keys {min, max}
+    uint32_t *d_mm = nullptr;  // [RSSEG_MM_REPL][RSSEG_MM_PLANES][2] ordered keys {min, max}
     int mm_count = 0;
     double mm_min[8], mm_max[8];
 };
 #define RSSEG_MM_PLANES 8
+#define RSSEG_MM_REPL 64   // replicas of the slot table, one 64-byte line each: a workgroup commits to replica blockIdx.x % 64
 int mm_begin(rsseg_ctx *ctx, int nplanes);   // reset the device slots before a producing launch (no-op when off)
 int mm_end(rsseg_ctx *ctx, int nplanes);     // read them back into ctx->mm_min / mm_max (after the launch)
 
@@ -165,6 +166,27 @@ __device__ __forceinline__ void mm_commit(uint32_t *slot, float mn, float mx)
         if (kmn < __builtin_nontemporal_load(&slot[0])) atomicMin(&slot[0], kmn);
         if (kmx > __builtin_nontemporal_load(&slot[1])) atomicMax(&slot[1], kmx);
     }
+}
+
+// the same once per WORKGROUP (every thread of the block must call it): a per-wave test makes tens of thousands of waves
+// read one address at the end of a kernel, ~0.3 ms whatever the raster size — a first-order term for the small stripes
+// of a sharded raster
+__device__ __forceinline__ void mm_commit_wg(uint32_t *slot, float mn, float mx)
+{
+    __shared__ float s_mn[16], s_mx[16];
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane_id() == 0) { s_mn[w] = mn; s_mx[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; i++) { mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); }
+        const uint32_t kmn = mm_key(mn), kmx = mm_key(mx);
+        uint32_t *rs = slot + (size_t)(blockIdx.x % RSSEG_MM_REPL) * (2 * RSSEG_MM_PLANES);   // this workgroup's replica
+        if (kmn < __builtin_nontemporal_load(&rs[0])) atomicMin(&rs[0], kmn);
+        if (kmx > __builtin_nontemporal_load(&rs[1])) atomicMax(&rs[1], kmx);
+    }
+    __syncthreads();
 }
 
 // round-to-nearest-even fixed point, quantum 2^-40, exact for |x| < 2^11:

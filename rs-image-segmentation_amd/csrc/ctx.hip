@@ -185,7 +185,7 @@ extern "C" int rsseg_ctx_collect_minmax(rsseg_ctx *ctx, int on)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (on && !ctx->d_mm) HIPCHK(ctx, hipMalloc((void **)&ctx->d_mm, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES));
+    if (on && !ctx->d_mm) HIPCHK(ctx, hipMalloc((void **)&ctx->d_mm, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES * RSSEG_MM_REPL));
     ctx->mm_collect = on != 0;
     ctx->mm_count = 0;
     return RSSEG_OK;
@@ -206,8 +206,8 @@ int mm_begin(rsseg_ctx *ctx, int nplanes)
     if (!ctx->mm_collect) return RSSEG_OK;
     // slot layout {min key, max key} per plane: 0xffffffff / 0 via two strided fills would need a kernel; one 2-D memset
     // does it without touching host memory (no synchronisation): bytes 0..3 of each 8-byte slot = 0xff, 4..7 = 0x00
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_mm, 0, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES, ctx->stream));
-    HIPCHK(ctx, hipMemset2DAsync(ctx->d_mm, 8, 0xff, 4, RSSEG_MM_PLANES, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_mm, 0, sizeof(uint32_t) * 2 * RSSEG_MM_PLANES * RSSEG_MM_REPL, ctx->stream));
+    HIPCHK(ctx, hipMemset2DAsync(ctx->d_mm, 8, 0xff, 4, RSSEG_MM_PLANES * RSSEG_MM_REPL, ctx->stream));
     (void)nplanes;
     return RSSEG_OK;
 }
@@ -215,9 +215,17 @@ int mm_begin(rsseg_ctx *ctx, int nplanes)
 int mm_end(rsseg_ctx *ctx, int nplanes)
 {
     if (!ctx->mm_collect) return RSSEG_OK;
-    uint32_t k[2 * RSSEG_MM_PLANES];
-    HIPCHK(ctx, hipMemcpyAsync(k, ctx->d_mm, sizeof(k), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t kr[2 * RSSEG_MM_PLANES * RSSEG_MM_REPL], k[2 * RSSEG_MM_PLANES];
+    HIPCHK(ctx, hipMemcpyAsync(kr, ctx->d_mm, sizeof(kr), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < RSSEG_MM_PLANES; i++) {   // the replicas of a slot: smallest min key, largest max key
+        k[2 * i] = 0xffffffffu;
+        k[2 * i + 1] = 0;
+        for (int r = 0; r < RSSEG_MM_REPL; r++) {
+            k[2 * i] = std::min(k[2 * i], kr[(r * RSSEG_MM_PLANES + i) * 2]);
+            k[2 * i + 1] = std::max(k[2 * i + 1], kr[(r * RSSEG_MM_PLANES + i) * 2 + 1]);
+        }
+    }
     auto unkey = [](uint32_t key) {
         uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
         float f;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
     }
     if (MM) {
 #pragma unroll
-        for (int j = 0; j < 7; j++) mm_commit(mm + 2 * j, lmn[j], lmx[j]);
+        for (int j = 0; j < 7; j++) mm_commit_wg(mm + 2 * j, lmn[j], lmx[j]);
     }
 }
 

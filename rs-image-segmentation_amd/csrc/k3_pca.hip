@@ -225,7 +225,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
     if (MM) {
 #pragma unroll
         for (int cc = 0; cc < PCA_MAXB; cc++)
-            if (cc < pr.nc) mm_commit(mm + 2 * cc, lmn[cc], lmx[cc]);
+            if (cc < pr.nc) mm_commit_wg(mm + 2 * cc, lmn[cc], lmx[cc]);
     }
 }
 

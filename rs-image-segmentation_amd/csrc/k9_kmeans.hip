@@ -958,18 +958,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const int nblk = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n, (int64_t)KM_THREADS * vt<T>::PXL)));
     const int M = KMAX * F + KMAX + 1;
 
-    // ---- rank geometry ----
+    // ---- rank geometry: every rank's pixel count travels in the MinMax all-reduce below (one collective fewer) ----
     int64_t n_all[RSSEG_MAX_RANKS] = {0};
     n_all[ctx->rank] = n;
-    RSCHK(comm_allreduce_host(ctx, n_all, ctx->world, RSSEG_I64, RSSEG_SUM));
     int64_t N = 0, offset = 0;
-    for (int r = 0; r < ctx->world; r++) {
-        if (r < ctx->rank) offset += n_all[r];
-        N += n_all[r];
-    }
-    if (N <= 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: no pixels");
-    if (N < k) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_samples=%lld should be >= n_clusters=%d", (long long)N, k);
-
     // ---- workspace layout ----
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
@@ -988,7 +980,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_closest = carve(dist_stride);            // the ONE closest-distance plane of k-means++
     const size_t o_lab = carve((size_t)std::max<int64_t>(n, 1) + 64);
     RSCHK(ws_reserve(ctx, off));
-    const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F,
+    const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F + sizeof(double) * RSSEG_MAX_FEATURES + 64,
                                               sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
                                               sizeof(long long) * 2 * (size_t)M, (size_t)65536});
     RSCHK(pin_reserve(ctx, pin_need));
@@ -1028,7 +1020,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
         const T *hmn = (const T *)ctx->h_pin, *hmx = hmn + (size_t)nblk * F;
-        double mm[2 * RSSEG_MAX_FEATURES];
+        double mm[2 * RSSEG_MAX_FEATURES + RSSEG_MAX_RANKS];
         for (int f = 0; f < F; f++) {
             T mn = (T)INFINITY, mx = (T)-INFINITY;
             if (n > 0 && known) {
@@ -1042,7 +1034,15 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             mm[f] = -(double)mn;  // MAX-reduce of the negated minimum
             mm[F + f] = (double)mx;
         }
-        RSCHK(comm_allreduce_host(ctx, mm, 2 * F, RSSEG_F64, RSSEG_MAX));
+        for (int r = 0; r < ctx->world; r++) mm[2 * F + r] = r == ctx->rank ? (double)n : 0.0;   // exact below 2^53; MAX of {n, 0, ...}
+        RSCHK(comm_allreduce_host(ctx, mm, 2 * F + ctx->world, RSSEG_F64, RSSEG_MAX));
+        for (int r = 0; r < ctx->world; r++) {
+            n_all[r] = (int64_t)mm[2 * F + r];
+            if (r < ctx->rank) offset += n_all[r];
+            N += n_all[r];
+        }
+        if (N <= 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: no pixels");
+        if (N < k) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_samples=%lld should be >= n_clusters=%d", (long long)N, k);
         for (int f = 0; f < F; f++) {
             volatile T mn = (T)(-mm[f]), mx = (T)mm[F + f];
             volatile T range = mx - mn;
@@ -1058,14 +1058,31 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
 
     // ---- X.mean(axis=0) and np.var(X, axis=0) with exact sums ----
     const T Nt = (T)N;
+    // The first k-means++ centre (RandomState.choice over N equal weights: the first draw of the generator) is known as
+    // soon as N is; its row rides on the mean all-reduce: the owner gathers the scaled, NOT yet centred row (the scaler on
+    // the device still has mean 0), every rank adds the bit patterns (zeros elsewhere), the host subtracts the mean in T.
+    mt19937 rng(seed);
+    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+    int64_t init_idx[RSSEG_MAX_CLUSTERS];
+    {
+        const double u0 = rng.random_sample();
+        init_idx[0] = uniform_choice(N, std::is_same<T, float>::value ? RSSEG_F32 : RSSEG_F64, u0);
+        if (init_idx[0] >= N) init_idx[0] = N - 1;
+    }
+    T row0_raw[RSSEG_MAX_FEATURES];
     auto mean_pass = [&](i128 *sums) -> int {
+        const int64_t li0 = init_idx[0] - offset;
+        const bool own0 = li0 >= 0 && li0 < n;
+        const size_t mom_bytes = sizeof(long long) * (size_t)nblk * F;
         if (n > 0) {
             hipLaunchKernelGGL((km_moment<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            if (own0) hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li0, d_sp, d_row);
             HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, sizeof(long long) * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, mom_bytes, hipMemcpyDeviceToHost, st));
+            if (own0) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + mom_bytes, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
         }
-        long long lim[2 * RSSEG_MAX_FEATURES];
+        long long lim[3 * RSSEG_MAX_FEATURES];
         const long long *hp = (const long long *)ctx->h_pin;
         for (int f = 0; f < F; f++) {
             i128 s = 0;
@@ -1073,9 +1090,17 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 for (int b = 0; b < nblk; b++) s += hp[(size_t)f * nblk + b];
             lim[2 * f] = (long long)(s >> 32);
             lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
+            double rv = own0 ? (double)((const T *)(ctx->h_pin + mom_bytes))[f] : 0.0;
+            if (rv == 0.0) rv = 0.0;   // -0.0 would not survive the integer sum as a zero
+            memcpy(&lim[2 * F + f], &rv, 8);
         }
-        RSCHK(comm_allreduce_host(ctx, lim, 2 * F, RSSEG_I64, RSSEG_SUM));
-        for (int f = 0; f < F; f++) sums[f] = limbs(lim[2 * f], lim[2 * f + 1]);
+        RSCHK(comm_allreduce_host(ctx, lim, 3 * F, RSSEG_I64, RSSEG_SUM));
+        for (int f = 0; f < F; f++) {
+            sums[f] = limbs(lim[2 * f], lim[2 * f + 1]);
+            double rv;
+            memcpy(&rv, &lim[2 * F + f], 8);
+            row0_raw[f] = (T)rv;
+        }
         return RSSEG_OK;
     };
     i128 sums[RSSEG_MAX_FEATURES];
@@ -1096,10 +1121,6 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     }
 
     // ---- k-means++ (_kmeans.py:213-270) ----
-    mt19937 rng(seed);
-    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
-    int64_t init_idx[RSSEG_MAX_CLUSTERS];
-
     // fetch scaled+centred rows of global pixel indices; every rank ends up with all rows
     auto fetch_rows = [&](const int64_t *gidx, int cnt, T rows[][RSSEG_MAX_FEATURES]) -> int {
         double buf[KPP_MAXL * RSSEG_MAX_FEATURES];
@@ -1150,29 +1171,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         }
         return RSSEG_OK;
     };
-    auto global_total = [&](int row, u128 *rank_tot /*[world]*/, u128 *total) -> int {
-        u128 loc = 0;
-        if (n > 0)
-            for (int64_t c = 0; c < nchunks; c++) loc += h_part[(size_t)row * nchunks + c];
-        long long lim[2 * RSSEG_MAX_RANKS];
-        memset(lim, 0, sizeof(lim));
-        lim[2 * ctx->rank] = (long long)(loc >> 32);
-        lim[2 * ctx->rank + 1] = (long long)(loc & 0xffffffffull);
-        RSCHK(comm_allreduce_host(ctx, lim, 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
-        *total = 0;
-        for (int r = 0; r < ctx->world; r++) {
-            rank_tot[r] = ((u128)(unsigned long long)lim[2 * r] << 32) + (u128)(unsigned long long)lim[2 * r + 1];
-            *total += rank_tot[r];
-        }
-        return RSSEG_OK;
-    };
 
     {
-        const double u0 = rng.random_sample();
-        init_idx[0] = uniform_choice(N, std::is_same<T, float>::value ? RSSEG_F32 : RSSEG_F64, u0);
-        if (init_idx[0] >= N) init_idx[0] = N - 1;
         T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
-        RSCHK(fetch_rows(init_idx, 1, rows));
+        for (int f = 0; f < F; f++) {   // the centring the device applies: fl(fl(fl(x * scale) + min) - mean)
+            volatile T v = row0_raw[f] - sp.mean[f];
+            rows[0][f] = v;
+        }
         for (int f = 0; f < F; f++) C[0][f] = rows[0][f];
         RSCHK(upload_cands(rows, 1, nullptr));
         if (n > 0) {
@@ -1182,8 +1187,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         HIPCHK(ctx, hipGetLastError());
     }
     RSCHK(pull_partials(1 + F));
-    {   // np.var(X, axis=0) from rows 1..F of the partials
-        long long lim[2 * RSSEG_MAX_FEATURES];
+    u128 rank_tot[RSSEG_MAX_RANKS], total = 0;
+    {   // np.var(X, axis=0) from rows 1..F of the partials, and every rank's total of row 0 (the potential of the first
+        // centre), in ONE all-reduce
+        long long lim[2 * RSSEG_MAX_FEATURES + 2 * RSSEG_MAX_RANKS];
+        memset(lim, 0, sizeof(lim));
         for (int f = 0; f < F; f++) {
             i128 s = 0;
             if (n > 0)
@@ -1191,7 +1199,12 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             lim[2 * f] = (long long)(s >> 32);
             lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
         }
-        RSCHK(comm_allreduce_host(ctx, lim, 2 * F, RSSEG_I64, RSSEG_SUM));
+        u128 loc = 0;
+        if (n > 0)
+            for (int64_t c = 0; c < nchunks; c++) loc += h_part[c];
+        lim[2 * F + 2 * ctx->rank] = (long long)(loc >> 32);
+        lim[2 * F + 2 * ctx->rank + 1] = (long long)(loc & 0xffffffffull);
+        RSCHK(comm_allreduce_host(ctx, lim, 2 * F + 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
         T var[RSSEG_MAX_FEATURES];
         for (int f = 0; f < F; f++) {
             volatile T s = fixed_to_T<T>(limbs(lim[2 * f], lim[2 * f + 1]));
@@ -1203,9 +1216,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         volatile T t = m2 * (T)tol_in;
         tol = t;
         if (info) info->tol = (double)tol;
+        for (int r = 0; r < ctx->world; r++) {
+            rank_tot[r] = ((u128)(unsigned long long)lim[2 * F + 2 * r] << 32) + (u128)(unsigned long long)lim[2 * F + 2 * r + 1];
+            total += rank_tot[r];
+        }
     }
-    u128 rank_tot[RSSEG_MAX_RANKS], total;
-    RSCHK(global_total(0, rank_tot, &total));
     T current_pot = (T)((double)total * (1.0 / 1099511627776.0));
     std::vector<unsigned long long> prefix_part((size_t)nchunks);  // this rank's closest-dist chunk sums
     for (int64_t c = 0; c < nchunks; c++) prefix_part[c] = h_part[c];

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rsseg_u8_to_unit_f32": (_int, [_vp, _vp, _i64, _vp]),
     "rsseg_resize_bilinear_f32": (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
     "rsseg_resize_bilinear_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _int, _int, _int]),
+    "rsseg_resize_bilinear_rows_multi_f32": (_int, [_vp, _PP, _int, _int, _int, _int, _int, _PP, _int, _int, _int, _int]),
     "rsseg_box_mean_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "rsseg_box_mean_rows_f32": (_int, [_vp, _PP, _int, _int, _int, _int, _int, _int, _int, _int, _int, _PP]),
     "rsseg_local_std_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),

@@ -127,7 +127,7 @@ def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size
     small, (oh, ow) = ctx.glcm(q, H, W, levels, window_size, step_size)
     if not upsample:
         return dict(zip(GLCM_NAMES, small)), (oh, ow)
-    return {k: ctx.resize_bilinear(v, oh, ow, H, W) for k, v in zip(GLCM_NAMES, small)}, (oh, ow)
+    return dict(zip(GLCM_NAMES, ctx.resize_bilinear_multi(small, oh, ow, 0, oh, H, W, 0, H))), (oh, ow)   # five maps, one launch
 
 
 def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=21, glcm_step=21, glcm_levels=32,
@@ -146,25 +146,28 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
     else:
         qb = band_quantile_bundles(ctx, bands, n_global)
         lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
-        idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
-        norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
         fused = all(q["center"] is not None for q in qb)
-        pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, [(q["center"], q["scale"]) for q in qb] if fused else None)
-        nir2 = None
+        if fused:
+            # one grouped select serves every percentile; the PCA normalises the RAW bands inside its kernels (no
+            # normalised planes are written, no range pass), only the normalised NIR band is kept for the texture chain
+            idx, norms = spectral_indices(ctx, bands, lohi, want_norm=tuple(i == 3 for i in range(5)))
+            pcs, ratio, model = pca(ctx, bands, None, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
+            nir2 = ctx.normalize(norms[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]), out=norms[3])
+            norm_all = None
+        else:  # a band with NaNs: separate selects on the normalised planes
+            idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
+            norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
+            pcs, ratio, model = pca(ctx, norm_all, None, True, n_global, None)
+            nir2 = renormalize(ctx, norm_all[3], n_global)
     level1 = [idx["ndwi"], idx["mndwi"], idx["ndvi"], idx["evi"], idx["ndbi"], idx["bsi"], pcs[0]]
     ctx_planes = ctx.box_mean_multi(level1, H, W, 7, L.BORDER_REFLECT)   # the 7 channels of add_spatial_context in one launch
-    if nir2 is None:
-        if fused:
-            nir2 = ctx.normalize(norm_all[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]))
-        else:
-            nir2 = renormalize(ctx, norm_all[3], n_global)
     glcm, _ = glcm_features(ctx, nir2, H, W, glcm_levels, glcm_window, glcm_step)
     q255 = ctx.quantize_u8(nir2, 255.0)
     grad = ctx.morph_gradient(q255, H, W, 5)
     std5 = ctx.local_std(nir2, H, W, 5)
     sob = ctx.sobel_mag(q255, H, W)
     planes = level1 + ctx_planes + [glcm["contrast"], glcm["homogeneity"], grad, std5, sob]
-    extras = dict(indices=idx, norm=norm_all, pca=pcs, pca_ratio=ratio, pca_model=model, glcm=glcm, lohi=lohi, nir2=nir2, q255=q255)
+    extras = dict(indices=idx, pca=pcs, pca_ratio=ratio, pca_model=model, glcm=glcm, lohi=lohi, nir2=nir2, q255=q255)
     return planes, extras
 
 
@@ -323,7 +326,7 @@ def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: 
     qv = q[skip * W:(skip + need_i1 - need_i0) * W]
     small, (oh, ow) = ctx.glcm(qv, need_i1 - need_i0, W, 32, glcm_window, glcm_step)
     sh = (H - glcm_window) // glcm_step + 1
-    glcm = [ctx.resize_bilinear_rows(m, oh, ow, j0, sh, r1 - r0, W, r0, H) for m in small]
+    glcm = ctx.resize_bilinear_multi(small, oh, ow, j0, sh, r1 - r0, W, r0, H)
     planes = [idx[n] for n in INDEX_NAMES] + glcm + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes
@@ -401,7 +404,7 @@ def stack19_striped(ctx: Context, bands_ext: Sequence, H: int, W: int, r0: int, 
     q = ctx.quantize_u8(_rows_view(nir2, W, i0 - t0, i1 - t0), float(glcm_levels - 1))
     small, (oh, ow) = ctx.glcm(q, i1 - i0, W, glcm_levels, glcm_window, glcm_step)
     sh = (H - glcm_window) // glcm_step + 1
-    glcm = dict(zip(GLCM_NAMES, [ctx.resize_bilinear_rows(m, oh, ow, j0, sh, r1 - r0, W, r0, H) for m in small]))
+    glcm = dict(zip(GLCM_NAMES, ctx.resize_bilinear_multi(small, oh, ow, j0, sh, r1 - r0, W, r0, H)))
     nir_m = _rows_view(nir2, W, m0 - t0, m1 - t0)
     edges_m = (1 if m0 == 0 else 0) | (2 if m1 == H else 0)
     rows_m = (r0 - m0, r1 - m0)

@@ -329,6 +329,15 @@ class Context:
     def _rows(H, rows):
         return (0, H) if rows is None else (int(rows[0]), int(rows[1]))
 
+    def resize_bilinear_multi(self, srcs: Sequence, sh_local: int, sw: int, src_row0: int, sh: int, dh_local: int, dw: int, dst_row0: int, dh: int):
+        """cv2.resize(INTER_LINEAR) of up to 8 maps of one shape in one launch (rows form; full maps: src_row0 = dst_row0 = 0)."""
+        torch = _torch()
+        dsts = [self.empty(dh_local * dw, torch.float32) for _ in srcs]
+        self._chk(self.lib.rsseg_resize_bilinear_rows_multi_f32(self.h, self._pp(srcs), len(srcs), sh_local, sw, src_row0, sh, self._pp(dsts), dh_local,
+                                                                dw, dst_row0, dh))
+        self._tag_minmax(dsts)
+        return dsts
+
     def box_mean(self, plane, H: int, W: int, k: int, border: int, square: bool = False, rows=None, edges: int = 3):
         return self.box_mean_multi([plane], H, W, k, border, square, rows, edges)[0]
 
