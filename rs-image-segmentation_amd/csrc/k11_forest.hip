@@ -186,19 +186,17 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
     for (int g = 0; g < n_groups; g++) {
         const rf_group gr = groups[g];
         // the next group's nodes: one contiguous range, 16-byte loads, held in registers during the walk
-        uint4 pre[RF_NPRE];
+        // six named registers, not an array: the compiler kept `uint4 pre[6]` in scratch memory across the walk (96 bytes
+        // per lane written and read back per group = 800 B/px of HBM traffic: profiles/r02_c5_pmc_traffic.md, first r02 set)
+        static_assert(RF_NPRE == 6, "the prefetch registers below are spelled out for six pieces per thread");
         const bool more = g + 1 < n_groups;
-        int npiece = 0;
-        if (more) {
-            const rf_group gn = groups[g + 1];
-            npiece = (gn.n_nodes + 1) / 2;
-            const uint4 *src = reinterpret_cast<const uint4 *>(nodes + gn.node_base);
-#pragma unroll
-            for (int r = 0; r < RF_NPRE; r++) {
-                const int j = threadIdx.x + r * RF_LT;
-                if (j < npiece) pre[r] = src[j];
-            }
-        }
+        const rf_group gn = groups[more ? g + 1 : g];
+        const int npiece = more ? (gn.n_nodes + 1) / 2 : 0;
+        const uint4 *psrc = reinterpret_cast<const uint4 *>(nodes + gn.node_base);
+        const int plast = (gn.n_nodes + 1) / 2 - 1;
+#define RF_PRE(r) const uint4 pre##r = psrc[(int)threadIdx.x + r * RF_LT < plast ? (int)threadIdx.x + r * RF_LT : plast];
+        RF_PRE(0) RF_PRE(1) RF_PRE(2) RF_PRE(3) RF_PRE(4) RF_PRE(5)
+#undef RF_PRE
         rf_node nd[RF_NCH];
         unsigned base[RF_C];
 #pragma unroll
@@ -214,8 +212,9 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
         }
         if (any_nan) rf_walk_lds<true>(nd, feat_tid, base);
         else rf_walk_lds<false>(nd, feat_tid, base);
-        // votes: the rows of all chains are requested now and added (in tree order) after the refill below, whose two
-        // barriers hide the latency of the gathers; NC > 8 would need too many registers and votes chain by chain
+        // refill first (frees the prefetch registers: holding them AND the vote rows spilled 96 bytes per lane to scratch
+        // memory, 800 B/px of extra HBM writes), then request the vote rows of all chains at once; the second barrier and
+        // the next group's set-up cover most of the gather latency, and the rows are added in tree order behind it
         constexpr bool PIPE = NC <= 8;
         double rows[PIPE ? RF_NCH : 1][NC];
         if (PIPE) {
@@ -228,13 +227,11 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
         }
         if (more) {
             __syncthreads();  // every wave is done with the current group
-#pragma unroll
-            for (int r = 0; r < RF_NPRE; r++) {
-                const int j = threadIdx.x + r * RF_LT;
-                if (j < npiece) top[j] = pre[r];
-            }
-            __syncthreads();
+#define RF_PUT(r) if ((int)threadIdx.x + r * RF_LT < npiece) top[threadIdx.x + r * RF_LT] = pre##r;
+            RF_PUT(0) RF_PUT(1) RF_PUT(2) RF_PUT(3) RF_PUT(4) RF_PUT(5)
+#undef RF_PUT
         }
+        if (more) __syncthreads();
         if (PIPE) {
 #pragma unroll
             for (int q = 0; q < RF_NCH; q++)
