@@ -24,7 +24,7 @@
 //   k11_forest_lds   trees are taken in groups of <= 4 consecutive trees whose nodes (contiguous in the node array) fit
 //                    the LDS beside the features; the whole group is copied with 16-byte loads (prefetched into
 //                    registers during the walk of the previous group) and every step is two ds_reads.  Measured
-//                    (profiles/r02_forest_pmc.md): the walk is VALU-issue-bound — LDS array 13 % busy, bank conflicts
+//                    (profiles/r02_c5_pmc_sq.md): the walk is VALU-issue-bound — LDS array 13 % busy, bank conflicts
 //                    2 % (neighbouring pixels share paths) — so the loop is written for instruction count: 9 VALU per
 //                    tree step.
 //   k11_forest_gen   any forest: the first ntop nodes of each of 4 trees in LDS, deeper nodes by global loads.
