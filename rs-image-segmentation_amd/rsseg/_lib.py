@@ -122,6 +122,13 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C rs-image-segmentation_amd/csrc).  There is no CPU fallback.")
+    try:
+        # torch-ROCm ships its own HIP runtime: load it FIRST, so that librsseg_hip.so binds to the runtime that owns
+        # the process's device state.  (Loaded the other way round — e.g. build() then smoke() in one process — the
+        # system libamdhip64 comes up first and hipGetDeviceCount reports "no ROCm-capable device".)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
