@@ -25,7 +25,7 @@ struct forest_dev {
     void *d_treeoff = nullptr;  // int64 classes[n_classes], then rf_tree[n_trees]
     void *d_groups = nullptr;   // rf_group[n_groups]: the LDS plan (k11_forest.hip); none when a tree exceeds the LDS area
     int n_groups = 0;
-    int n_trees = 0, n_classes = 0, n_features = 0;
+    int n_trees = 0, n_classes = 0, n_features = 0, max_depth = 0;
     int64_t n_nodes = 0;
     int64_t classes[64];
 };

@@ -124,26 +124,36 @@ __device__ __forceinline__ int rf_stage_features(const rf_planes &pl, int F, int
 #define RF_NCH (RF_PX * RF_C)
 
 template <bool NANS>
-__device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C])
+__device__ __forceinline__ void rf_round_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C])
+{
+    float x[RF_NCH];
+#pragma unroll
+    for (int q = 0; q < RF_NCH; q++)   // chain q: pixel q / RF_C of the thread, tree q % RF_C of the group
+        x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * (RF_LT * 4) + ((nd[q].bits >> 24) & 63u) * (RF_TH * 4));
+#pragma unroll
+    for (int q = 0; q < RF_NCH; q++) {
+        bool go_right = x[q] > nd[q].thr;
+        if (NANS) go_right = go_right || (x[q] != x[q] && !(nd[q].bits & RF_MISS));
+        const unsigned next = (nd[q].bits & 0xffffffu) + (go_right ? 1u : 0u);
+        lds_cnode *p = (lds_cnode *)(base[q % RF_C] + next * 8u);
+        nd[q].thr = p->thr;
+        nd[q].bits = p->bits;
+    }
+}
+
+// Leaves are fixed points, so for deep forests (`two`: the host sets it from the deepest tree) the exit test runs every
+// SECOND round: one test costs as much as a chain step, and a lane that reaches its last leaf after an odd number of
+// rounds merely repeats it once.  Shallow forests (the reference's bundled model: depth <= 5) keep the test every round.
+template <bool NANS>
+__device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C], bool two)
 {
     for (;;) {
         unsigned all = nd[0].bits;
 #pragma unroll
         for (int q = 1; q < RF_NCH; q++) all &= nd[q].bits;
         if (all & RF_LEAF) break;
-        float x[RF_NCH];
-#pragma unroll
-        for (int q = 0; q < RF_NCH; q++)   // chain q: pixel q / RF_C of the thread, tree q % RF_C of the group
-            x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * (RF_LT * 4) + ((nd[q].bits >> 24) & 63u) * (RF_TH * 4));
-#pragma unroll
-        for (int q = 0; q < RF_NCH; q++) {
-            bool go_right = x[q] > nd[q].thr;
-            if (NANS) go_right = go_right || (x[q] != x[q] && !(nd[q].bits & RF_MISS));
-            const unsigned next = (nd[q].bits & 0xffffffu) + (go_right ? 1u : 0u);
-            lds_cnode *p = (lds_cnode *)(base[q % RF_C] + next * 8u);
-            nd[q].thr = p->thr;
-            nd[q].bits = p->bits;
-        }
+        rf_round_lds<NANS>(nd, feat_tid, base);
+        if (two) rf_round_lds<NANS>(nd, feat_tid, base);
     }
 }
 
@@ -152,7 +162,8 @@ __device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat
 template <int NC>
 __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
                                                         const rf_tree *__restrict__ trees, const rf_group *__restrict__ groups, int n_groups,
-                                                        int cap2 /* node area in 16-byte pieces */, int n_trees, const double *__restrict__ leafval,
+                                                        int cap2 /* node area in 16-byte pieces */, int two_rounds, int n_trees,
+                                                        const double *__restrict__ leafval,
                                                         int n_classes, const long long *__restrict__ classes, long long *__restrict__ out)
 {
     extern __shared__ __align__(16) char smem[];
@@ -210,8 +221,8 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
                 nd[px * RF_C + c].bits = p->bits;
             }
         }
-        if (any_nan) rf_walk_lds<true>(nd, feat_tid, base);
-        else rf_walk_lds<false>(nd, feat_tid, base);
+        if (any_nan) rf_walk_lds<true>(nd, feat_tid, base, two_rounds != 0);
+        else rf_walk_lds<false>(nd, feat_tid, base, two_rounds != 0);
         // refill first (frees the prefetch registers: holding them AND the vote rows spilled 96 bytes per lane to scratch
         // memory, 800 B/px of extra HBM writes), then request the vote rows of all chains at once; the second barrier and
         // the next group's set-up cover most of the gather latency, and the rows are added in tree order behind it
@@ -412,6 +423,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     for (int c = 0; c < n_classes; c++) leaf[(size_t)c * NCP + c] = 1.0;
     std::vector<rf_tree> trees(n_trees);
     std::vector<int> order, newid;
+    int max_depth = 0;
     for (int t = 0; t < n_trees; t++) {
         const int64_t b = tree_off[t], e = tree_off[t + 1];
         const int cnt = (int)(e - b);
@@ -435,6 +447,14 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
         if ((int)order.size() != cnt) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: tree %d has unreachable nodes", t);
         trees[t].node_off = (int)b;
         trees[t].n_nodes = cnt;
+        {   // depth of the tree (breadth-first order: a child's depth is its parent's + 1)
+            std::vector<int> depth((size_t)cnt, 0);
+            for (int h = 0; h < cnt; h++) {
+                const int g = order[h];
+                if (left[b + g] != -1) depth[newid[left[b + g]]] = depth[newid[right[b + g]]] = depth[h] + 1;
+                max_depth = std::max(max_depth, depth[h]);
+            }
+        }
         trees[t].leaf_off = 0;
         trees[t].pad = 0;
         for (int h = 0; h < cnt; h++) {
@@ -508,6 +528,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     HIPCHK(ctx, hipMemcpy(fd.d_treeoff, classes, n_classes * sizeof(long long), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy((char *)fd.d_treeoff + n_classes * sizeof(long long), trees.data(), trees.size() * sizeof(rf_tree), hipMemcpyHostToDevice));
     fd.n_trees = n_trees;
+    fd.max_depth = max_depth;
     fd.n_classes = n_classes;
     fd.n_features = n_features;
     fd.n_nodes = nn;
@@ -543,7 +564,7 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
             HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             prof_scope ps(ctx, "forest");
             hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_LT), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees,
-                               (const rf_group *)fd.d_groups, fd.n_groups, cap / 2, fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes,
+                               (const rf_group *)fd.d_groups, fd.n_groups, cap / 2, fd.max_depth >= 10 ? 1 : 0, fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes,
                                (long long *)d_out);
             return RSSEG_OK;
         };
