@@ -443,6 +443,68 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
 }
 
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
+// One WAVE per window (levels <= 32, any window size < 256): the four angles' co-occurrence counts live in four private
+// 2 KB LDS tables of packed 16-bit counters (a window has fewer than 65536 pairs); no workgroup barrier anywhere — a wave's
+// LDS operations execute in order, so its own atomics are complete before its reads.  This is the reference's default
+// geometry (window 21, step 21: indices.py:248) — k4_glcm_wg spent most of its 21 us per window in 20 barriers.
+__global__ __launch_bounds__(256) void k4_glcm_wave(const uint8_t *__restrict__ q, int H, int W, int levels, int win, int step, int oh,
+                                                    int ow, glcm_out out, glcm_consts gc)
+{
+    __shared__ unsigned hist_all[4][4 * 512];  // [wave][angle][x * 32 + y packed two counters per dword]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long widx = (long long)blockIdx.x * 4 + wave;
+    if (widx >= (long long)oh * ow) return;
+    const int oy = (int)(widx / ow), ox = (int)(widx - (long long)oy * ow);
+    const uint8_t *wp = q + (size_t)(oy * step) * W + (size_t)ox * step;
+    unsigned *hist = hist_all[wave];
+#pragma unroll
+    for (int t = 0; t < 8; t++) reinterpret_cast<uint4 *>(hist)[t * 64 + lane] = make_uint4(0, 0, 0, 0);
+    long long sums[4][6];  // per angle: S1 S2 Hq M1 M2 Mx (this lane's share)
+    for (int a = 0; a < 4; a++) {
+        const int dr = a == 0 ? 0 : 1, dc = a == 0 ? 1 : (a == 1 ? 1 : (a == 2 ? 0 : -1));
+        const int r1 = dr > 0 ? win - dr : win, c0 = dc < 0 ? -dc : 0, c1 = dc > 0 ? win - dc : win;
+        const int pw = c1 - c0, P = r1 * pw;
+        int s1 = 0, s2 = 0, m1 = 0, m2 = 0, mx = 0;
+        long long hq = 0;
+        for (int p = lane; p < P; p += 64) {
+            const int r = p / pw, c = c0 + p - r * pw;
+            int x = wp[(size_t)r * W + c], y = wp[(size_t)(r + dr) * W + (c + dc)];
+            x = x > 31 ? 31 : x;   // the quantiser guarantees < levels; never index outside the table
+            y = y > 31 ? 31 : y;
+            const int bin = x * 32 + y;
+            atomicAdd(&hist[a * 512 + (bin >> 1)], 1u << (16 * (bin & 1)));
+            const int d = x > y ? x - y : y - x;
+            s1 += d; s2 += d * d; hq += c_glcm_hq[d];
+            m1 += x + y; m2 += x * x + y * y; mx += 2 * x * y;
+        }
+        sums[a][0] = s1; sums[a][1] = s2; sums[a][2] = hq; sums[a][3] = m1; sums[a][4] = m2; sums[a][5] = mx;
+    }
+    long long A[4];
+    for (int a = 0; a < 4; a++) {
+        const unsigned *h = hist + a * 512;
+        long long acc = 0;
+        for (int t = lane; t < 1024; t += 64) {
+            const int x = t >> 5, y = t & 31, u = y * 32 + x;
+            const long long g = (long long)((h[t >> 1] >> (16 * (t & 1))) & 0xffffu) + (long long)((h[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+            acc += g * g;
+        }
+        A[a] = wave_sum(acc);
+#pragma unroll
+        for (int t = 0; t < 6; t++) sums[a][t] = wave_sum(sums[a][t]);
+    }
+    if (lane == 0) {
+        const long long na = (long long)win * (win - 1), nb = (long long)(win - 1) * (win - 1);
+        glcm_group g0, g1;
+        g0.S1 = sums[0][0] + sums[2][0]; g0.S2 = sums[0][1] + sums[2][1]; g0.Hq = sums[0][2] + sums[2][2];
+        g0.sq = sqrt((double)A[0]) + sqrt((double)A[2]);
+        g1.S1 = sums[1][0] + sums[3][0]; g1.S2 = sums[1][1] + sums[3][1]; g1.Hq = sums[1][2] + sums[3][2];
+        g1.sq = sqrt((double)A[1]) + sqrt((double)A[3]);
+        double r[4];
+        for (int a = 0; a < 4; a++) r[a] = glcm_corr((a & 1) ? nb : na, sums[a][3], sums[a][4], sums[a][5]);
+        glcm_finish(g0, g1, na, nb, r[0], r[1], r[2], r[3], (size_t)oy * ow + ox, out, gc);
+    }
+}
+
 __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q, int H, int W, int levels, int win, int step,
                                                   int oh, int ow, glcm_out out, glcm_consts gc)
 {
@@ -544,8 +606,11 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         else if (win == 5) GLCM_THREAD(5);
         else if (win == 3) GLCM_THREAD(3);
         else {
-            if (ow > 2147483647 || oh > 65535) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: output map too tall for the workgroup-per-window kernel");
-            hipLaunchKernelGGL(k4_glcm_wg, dim3(ow, oh), dim3(256), sizeof(unsigned int) * levels * levels, ctx->stream, d_q, H, W,
+            if (levels <= 32 && win < 256) {
+                hipLaunchKernelGGL(k4_glcm_wave, dim3((unsigned)ceil_div64((int64_t)oh * ow, 4)), dim3(256), 0, ctx->stream, d_q, H, W, levels, win, step, oh,
+                                   ow, out, gc);
+            } else if (ow > 2147483647 || oh > 65535) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "glcm: output map too tall for the workgroup-per-window kernel");
+            else hipLaunchKernelGGL(k4_glcm_wg, dim3(ow, oh), dim3(256), sizeof(unsigned int) * levels * levels, ctx->stream, d_q, H, W,
                                levels, win, step, oh, ow, out, gc);
         }
     }
