@@ -51,6 +51,31 @@ struct win_planes {
     void *out[WIN_MAXP];
 };
 
+// XCD-aware block -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so a
+// row-major tile order puts horizontally adjacent tiles — which share the 128-byte lines their 4-column pads touch — on
+// DIFFERENT XCDs, and the tile below 64 workgroups later.  Each XCD gets a contiguous run of tiles instead: neighbours in x
+// follow each other on one XCD, and the halo rows of the tile above are still in that XCD's L2.  grid.x = 8 * chunk.
+struct tile_map {
+    int ntx, nt, chunk;
+};
+static inline tile_map make_tile_map(int nrows, int W)
+{
+    tile_map m;
+    m.ntx = (W + TW - 1) / TW;
+    m.nt = m.ntx * ((nrows + TH - 1) / TH);
+    m.chunk = (m.nt + 7) / 8;
+    return m;
+}
+__device__ __forceinline__ bool tile_of_block(const tile_map &m, int &x0, int &ty0)
+{
+    const int t = (int)(blockIdx.x & 7u) * m.chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= m.chunk || t >= m.nt) return false;
+    const int ty = t / m.ntx;
+    x0 = (t - ty * m.ntx) * TW;
+    ty0 = ty * TH;
+    return true;
+}
+
 template <typename E> struct vec4;
 template <> struct vec4<float> { typedef float4 type; };
 template <> struct vec4<uint8_t> { typedef uint32_t type; };
@@ -121,13 +146,14 @@ __device__ __forceinline__ void store4(uint8_t *out, int W, int orow, int col, c
 
 // ---- box mean (optionally of x*x), float64 sums: rows left-to-right, then rows top-to-bottom ----
 template <int K, bool SQ>
-__global__ __launch_bounds__(256) void k6_box(win_planes pl, int Hin, int W, int y0, int nrows, int mode)
+__global__ __launch_bounds__(256) void k6_box(win_planes pl, int Hin, int W, int y0, int nrows, int mode, tile_map tm)
 {
     constexpr int R = K / 2;
     __shared__ __align__(16) float tile[(TH + 2 * R) * TSTRIDE];
     const float *x = (const float *)pl.in[blockIdx.z];
     float *out = (float *)pl.out[blockIdx.z];
-    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    int x0, ty0;
+    if (!tile_of_block(tm, x0, ty0)) return;
     load_tile<float, R>(tile, x, Hin, W, mode, x0, y0 + ty0);
     __syncthreads();
     const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
@@ -167,11 +193,12 @@ __global__ __launch_bounds__(256) void k6_box(win_planes pl, int Hin, int W, int
 
 // variance_scale_k / std_dev_scale_k: max(blur(x*x) - blur(x)^2, 0) [sqrt], BORDER_REFLECT_101 (indices.py:537-548)
 template <int K, bool VAR>
-__global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int Hin, int W, int y0, int nrows, float *__restrict__ out)
+__global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int Hin, int W, int y0, int nrows, float *__restrict__ out, tile_map tm)
 {
     constexpr int R = K / 2;
     __shared__ __align__(16) float tile[(TH + 2 * R) * TSTRIDE];
-    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    int x0, ty0;
+    if (!tile_of_block(tm, x0, ty0)) return;
     load_tile<float, R>(tile, x, Hin, W, 1, x0, y0 + ty0);
     __syncthreads();
     const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
@@ -222,11 +249,12 @@ __global__ __launch_bounds__(256) void k6_std(const float *__restrict__ x, int H
 
 // erode (MODE 0: min), dilate (MODE 1: max), gradient (MODE 2: max - min) with a K x K rectangle
 template <int K, int MODE>
-__global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, int Hin, int W, int y0, int nrows, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, int Hin, int W, int y0, int nrows, uint8_t *__restrict__ out, tile_map tm)
 {
     constexpr int R = K / 2;
     __shared__ __align__(16) uint8_t tile[(TH + 2 * R) * TSTRIDE];
-    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    int x0, ty0;
+    if (!tile_of_block(tm, x0, ty0)) return;
     load_tile<uint8_t, R>(tile, q, Hin, W, BORDER_REPLICATE, x0, y0 + ty0);
     __syncthreads();
     const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
@@ -276,11 +304,12 @@ __global__ __launch_bounds__(256) void k7_morph(const uint8_t *__restrict__ q, i
 // once instead of being written, re-read and re-written as float32.
 template <int KIND, int PASS>
 __global__ __launch_bounds__(256) void k8_filter(const uint8_t *__restrict__ q, int Hin, int W, int y0, int nrows, float *__restrict__ out,
-                                                 float sub, float den, uint32_t *__restrict__ mm)
+                                                 float sub, float den, uint32_t *__restrict__ mm, tile_map tm)
 {
     constexpr int R = 1;
     __shared__ __align__(16) uint8_t tile[(TH + 2 * R) * TSTRIDE];
-    const int x0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    int x0, ty0;
+    if (!tile_of_block(tm, x0, ty0)) return;   // whole workgroup: uniform
     load_tile<uint8_t, R>(tile, q, Hin, W, 1, x0, y0 + ty0);
     __syncthreads();
     const int cx = (threadIdx.x & 63) * CPT, ry = (threadIdx.x >> 6) * RPT;
@@ -338,7 +367,7 @@ __global__ __launch_bounds__(256) void k8_filter(const uint8_t *__restrict__ q, 
         if (threadIdx.x == 0) {
             const float mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3])), mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
             const uint32_t kmn = mm_key(mn), kmx = mm_key(mx);
-            uint32_t *rs = mm + 16 * ((blockIdx.x + blockIdx.y * gridDim.x) % RSSEG_MM_REPL);   // 64 replicas, one line each
+            uint32_t *rs = mm + 16 * (blockIdx.x % RSSEG_MM_REPL);   // 64 replicas, one line each
             if (kmn < __builtin_nontemporal_load(&rs[0])) atomicMin(&rs[0], kmn);
             if (kmx > __builtin_nontemporal_load(&rs[1])) atomicMax(&rs[1], kmx);
         }
@@ -405,7 +434,6 @@ __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int s
 }
 
 static dim3 grid2d(int H, int W) { return dim3((W + WG_X - 1) / WG_X, (H + WG_Y - 1) / WG_Y); }
-static dim3 tile_grid(int nrows, int W, int nplanes = 1) { return dim3((W + TW - 1) / TW, (nrows + TH - 1) / TH, nplanes); }
 
 // rows form: the plane holds Hin rows; rows [y0, y1) are produced.  edges bit 0 / bit 1: row 0 / row Hin - 1 is the
 // image's first / last row (the border rule applies there); otherwise it is a halo row of a stripe and must be out of
@@ -437,11 +465,12 @@ extern "C" int rsseg_box_mean_rows_f32(rsseg_ctx *ctx, const float *const *d_x, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         prof_scope ps(ctx, nplanes > 1 ? "ctxmean" : "box");  // "ctxmean": several planes per launch (add_spatial_context)
-        const dim3 g = tile_grid(y1 - y0, W, nplanes);
-#define BOX_GO(KV)                                                                                                      \
-    case KV:                                                                                                            \
-        if (square) hipLaunchKernelGGL((k6_box<KV, true>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border); \
-        else hipLaunchKernelGGL((k6_box<KV, false>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border);      \
+        const tile_map tm = make_tile_map(y1 - y0, W);
+        const dim3 g(8 * tm.chunk, 1, nplanes);
+#define BOX_GO(KV)                                                                                                          \
+    case KV:                                                                                                                \
+        if (square) hipLaunchKernelGGL((k6_box<KV, true>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border, tm); \
+        else hipLaunchKernelGGL((k6_box<KV, false>), g, dim3(256), 0, ctx->stream, pl, Hin, W, y0, y1 - y0, border, tm);      \
         break;
         switch (k) { BOX_GO(3) BOX_GO(5) BOX_GO(7) BOX_GO(9) }
 #undef BOX_GO
@@ -465,11 +494,12 @@ extern "C" int rsseg_local_std_rows_f32(rsseg_ctx *ctx, const float *d_x, int Hi
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
         prof_scope ps(ctx, "box");
-        const dim3 g = tile_grid(y1 - y0, W);
-#define STD_GO(KV)                                                                                                \
-    case KV:                                                                                                      \
-        if (variance) hipLaunchKernelGGL((k6_std<KV, true>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out); \
-        else hipLaunchKernelGGL((k6_std<KV, false>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out);         \
+        const tile_map tm = make_tile_map(y1 - y0, W);
+        const dim3 g(8 * tm.chunk);
+#define STD_GO(KV)                                                                                                    \
+    case KV:                                                                                                          \
+        if (variance) hipLaunchKernelGGL((k6_std<KV, true>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out, tm); \
+        else hipLaunchKernelGGL((k6_std<KV, false>), g, dim3(256), 0, ctx->stream, d_x, Hin, W, y0, y1 - y0, d_out, tm);         \
         break;
         switch (k) { STD_GO(3) STD_GO(5) STD_GO(7) }
 #undef STD_GO
@@ -491,11 +521,12 @@ extern "C" int rsseg_local_var_f32(rsseg_ctx *ctx, const float *d_x, int H, int 
 template <int MODE> static int morph_launch(rsseg_ctx *ctx, const uint8_t *in, int Hin, int W, int y0, int y1, int k, uint8_t *out)
 {
     prof_scope ps(ctx, "morph");
-    const dim3 g = tile_grid(y1 - y0, W);
+    const tile_map tm = make_tile_map(y1 - y0, W);
+    const dim3 g(8 * tm.chunk);
     switch (k) {
-    case 3: hipLaunchKernelGGL((k7_morph<3, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
-    case 5: hipLaunchKernelGGL((k7_morph<5, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
-    case 7: hipLaunchKernelGGL((k7_morph<7, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out); break;
+    case 3: hipLaunchKernelGGL((k7_morph<3, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out, tm); break;
+    case 5: hipLaunchKernelGGL((k7_morph<5, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out, tm); break;
+    case 7: hipLaunchKernelGGL((k7_morph<7, MODE>), g, dim3(256), 0, ctx->stream, in, Hin, W, y0, y1 - y0, out, tm); break;
     }
     return RSSEG_OK;
 }
@@ -550,14 +581,15 @@ static int filter_rows(rsseg_ctx *ctx, const char *what, const uint8_t *d_q, int
     RSCHK(ws_reserve(ctx, 64 * RSSEG_MM_REPL));
     RSCHK(pin_reserve(ctx, 64 * RSSEG_MM_REPL));
     uint32_t *d_keys = (uint32_t *)ctx->d_ws;   // [RSSEG_MM_REPL] lines of {min key, max key, ...}
-    const dim3 g = tile_grid(std::max(y1 - y0, 1), W);
+    const tile_map tm = make_tile_map(std::max(y1 - y0, 1), W);
+    const dim3 g(8 * tm.chunk);
     double mm[2] = {-INFINITY, -INFINITY};  // {-(min), max}: a rank without rows contributes nothing to the MAX-reduce
     if (y1 > y0) {
         HIPCHK(ctx, hipMemsetAsync(d_keys, 0, 64 * RSSEG_MM_REPL, ctx->stream));
         HIPCHK(ctx, hipMemset2DAsync(d_keys, 64, 0xff, 4, RSSEG_MM_REPL, ctx->stream));
         {
             prof_scope ps(ctx, "filt_max");
-            hipLaunchKernelGGL((k8_filter<KIND, 0>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, (float *)nullptr, 0.f, 1.f, d_keys);
+            hipLaunchKernelGGL((k8_filter<KIND, 0>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, (float *)nullptr, 0.f, 1.f, d_keys, tm);
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_keys, 64 * RSSEG_MM_REPL, hipMemcpyDeviceToHost, ctx->stream));
@@ -592,7 +624,7 @@ static int filter_rows(rsseg_ctx *ctx, const char *what, const uint8_t *d_q, int
     }
     {
         prof_scope ps(ctx, "filt_write");
-        hipLaunchKernelGGL((k8_filter<KIND, 1>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, d_out, sub, den, (uint32_t *)nullptr);
+        hipLaunchKernelGGL((k8_filter<KIND, 1>), g, dim3(256), 0, ctx->stream, d_q, Hin, W, y0, y1 - y0, d_out, sub, den, (uint32_t *)nullptr, tm);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
