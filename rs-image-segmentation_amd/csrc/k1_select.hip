@@ -19,6 +19,11 @@ __device__ __forceinline__ uint32_t f32_key(float x, bool &is_nan)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// pass 3 (tried FIRST): small-integer planes.  The reference's preprocessed tiles are uint8 digital numbers stored as float32
+//         (preprocessing.py:117-118, 144): when every value of a plane is an integer in [0, 2048) or NaN, ONE pass with
+//         bin = (int)value resolves every rank exactly (value = bin) — one read of the plane and one all-reduce instead of
+//         three.  The first value that does not qualify raises a flag in global memory and every workgroup stops at its next
+//         batch, so planes of general floats pay ~1 % of a pass before the three radix passes below take over.
 // pass 0: bin = key >> 21 (one table).
 // pass 1: prefix = key >> 21 (11 bits), bin = (key >> 10) & 2047, one 2048-bin table per live prefix.
 // pass 2: prefix = key >> 10 (22 bits), bin = key & 1023.
@@ -44,15 +49,15 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
                                                        unsigned long long *__restrict__ nan_count)
 {
     extern __shared__ uint32_t lh[];  // [ntab][SEL_BINS] counters, then the byte lookup tables
-    const int ntab = PASS == 0 ? 1 : nprefix;
-    const int nb = PASS == 0 ? P0_COPIES * P0_STRIDE : ntab * SEL_BINS;
+    const int ntab = (PASS == 0 || PASS == 3) ? 1 : nprefix;
+    const int nb = (PASS == 0 || PASS == 3) ? P0_COPIES * P0_STRIDE : ntab * SEL_BINS;
     const uint32_t my_copy = (threadIdx.x & (P0_COPIES - 1)) * P0_STRIDE;
     uint8_t *tab1 = reinterpret_cast<uint8_t *>(lh + nb);  // [2048]
     uint8_t *tab2 = tab1 + SEL_BINS;                       // [n1][2048], pass 2 only
     __shared__ uint32_t p1list[RSSEG_MAX_RANKS];
     __shared__ int n1s;
     for (int i = threadIdx.x; i < nb; i += THREADS) lh[i] = 0;
-    if (PASS != 0) {
+    if (PASS != 0 && PASS != 3) {
         for (int i = threadIdx.x; i < SEL_BINS; i += THREADS) tab1[i] = SEL_NONE;
         if (threadIdx.x == 0) {
             int n1 = 0;  // distinct 11-bit prefixes
@@ -81,13 +86,19 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
         }
     }
     __syncthreads();
-    uint32_t my_nan = 0;
+    uint32_t my_nan = 0, my_bad = 0;
     const int64_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     auto handle = [&](float v) {
         bool isn;
         uint32_t k = f32_key(v, isn);
         if (isn) my_nan++;
+        if (PASS == 3) {
+            const bool ok = !isn && v >= 0.f && v < (float)SEL_BINS && truncf(v) == v;   // -0.0 counts as 0, like the radix key
+            if (!isn && !ok) my_bad++;
+            if (ok) atomicAdd(&lh[my_copy + swz((uint32_t)(int)v)], 1u);
+            return;
+        }
         bool want = !isn;
         uint32_t idx = 0;
         if (PASS == 0) {
@@ -109,6 +120,10 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
         const int64_t stride = (int64_t)gridDim.x * THREADS;
         int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
         for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {  // UNR 16-byte loads in flight per lane
+            if (PASS == 3) {   // give up as soon as any workgroup met a value that is not a small integer
+                if (my_bad) __builtin_nontemporal_store(1ull, nan_count + 2);
+                if (__builtin_nontemporal_load(nan_count + 2)) break;
+            }
             float4 v[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; u++) v[u] = x4[i + u * stride];
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) handle(x[(n4 << 2) + threadIdx.x]);
     __syncthreads();
-    if (PASS == 0) {
+    if (PASS == 0 || PASS == 3) {
         for (int i = threadIdx.x; i < SEL_BINS; i += THREADS) {
             uint32_t c = 0;
 #pragma unroll
@@ -135,9 +150,13 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
             if (c) atomicAdd(&hist[(i & ~(SEL_BINS - 1)) + swz(i & (SEL_BINS - 1))], (unsigned long long)c);
         }
     }
-    if (PASS == 0) {
+    if (PASS == 0 || PASS == 3) {
         uint32_t t = wave_sum(my_nan);
         if (lane_id() == 0 && t) atomicAdd(nan_count, (unsigned long long)t);
+    }
+    if (PASS == 3) {
+        uint32_t t = wave_sum(my_bad);
+        if (lane_id() == 0 && t) atomicAdd(nan_count + 1, (unsigned long long)t);
     }
 }
 
@@ -175,7 +194,8 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
 #define SEL_ATTR(TH)                                                                                                       \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<0, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));    \
     HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<1, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l1));    \
-    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<2, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l2));    \
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k1_hist<3, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l0));
         SEL_ATTR(1024)
         attr_done[ctx->device & 63] = true;
     }
@@ -187,7 +207,8 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     do {                                     \
         if (pass == 0) SEL_GO(0, TH);        \
         else if (pass == 1) SEL_GO(1, TH);   \
-        else SEL_GO(2, TH);                  \
+        else if (pass == 2) SEL_GO(2, TH);   \
+        else SEL_GO(3, TH);                  \
     } while (0)
         SEL_PASS(1024);
     };
@@ -202,6 +223,46 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     std::vector<plane_state> st((size_t)P);
     std::vector<uint32_t> h_pre((size_t)P * 64);
 
+    {   // ---- small-integer fast path (pass 3): one read of every plane, one all-reduce ----
+        const size_t used = 8 + SEL_BINS;
+        HIPCHK(ctx, hipMemsetAsync(d_hist_all, 0, (size_t)P * hist_bytes, ctx->stream));
+        for (int p = 0; p < P; p++) {
+            prof_scope ps(ctx, "select");
+            unsigned long long *d_nan = d_hist_all + (size_t)p * hist_elems;
+            launch(d_planes[p], 3, (size_t)P0_COPIES * P0_STRIDE * sizeof(uint32_t), d_pre_all, 1, d_nan + 8, d_nan);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpy2DAsync(h_hist_all, used * 8, d_hist_all, hist_bytes, used * 8, (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * used), RSSEG_I64, RSSEG_SUM));
+        bool small_ints = true;
+        for (int p = 0; p < P; p++) small_ints = small_ints && h_hist_all[(size_t)p * used + 1] == 0 && h_hist_all[(size_t)p * used + 2] == 0;
+        if (small_ints) {
+            for (int p = 0; p < P; p++) {
+                const long long *h_nanp = h_hist_all + (size_t)p * used, *h = h_nanp + 8;
+                const int64_t *rk = ranks + (size_t)p * nranks;
+                int64_t n_global = h_nanp[0];
+                for (int b = 0; b < SEL_BINS; b++) n_global += h[b];
+                for (int r = 0; r < nranks; r++) {
+                    if (rk[r] < 0 || rk[r] >= n_global)
+                        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: rank %lld outside [0,%lld)", (long long)rk[r], (long long)n_global);
+                    float v = __builtin_nanf("");
+                    if (rk[r] < n_global - h_nanp[0]) {   // NaNs sort last
+                        int64_t acc = 0;
+                        int b = 0;
+                        for (; b < SEL_BINS; b++) {
+                            if (rk[r] < acc + h[b]) break;
+                            acc += h[b];
+                        }
+                        v = (float)b;
+                    }
+                    out_values[(size_t)p * nranks + r] = v;
+                }
+                if (n_nan_out) n_nan_out[p] = h_nanp[0];
+            }
+            return RSSEG_OK;
+        }
+    }
     for (int pass = 0; pass < 3; pass++) {
         int live = 0;
         for (int p = 0; p < P; p++) {

@@ -65,6 +65,35 @@ def test_order_stats_general_floats_and_nan(ctx):
         ctx.order_stats(dev(ctx, a), [a.size])
 
 
+def test_order_stats_small_integer_fast_path_and_fallback(ctx):
+    """Planes of small non-negative integers (the reference's uint8 digital numbers stored as float32) resolve in one pass;
+    any other value — a fraction, a negative, 2048 or more, an infinity — anywhere in the plane sends the call through the
+    three radix passes.  Both routes against np.sort, with NaNs (sorted last) and -0.0."""
+    rng = np.random.default_rng(11)
+    n = 300007
+    base = rng.integers(0, 256, n).astype(np.float32)
+    base[5] = -0.0
+    ranks = [0, 1, n // 50, n // 2, n - n // 50, n - 1]
+    cases = {"ints": base.copy()}
+    for name, (pos, val) in {"fraction_late": (n - 3, 7.5), "negative": (n // 3, -1.0), "too_big": (17, 2048.0), "inf": (n // 2, np.inf),
+                             "max_ok": (9, 2047.0)}.items():
+        a = base.copy()
+        a[pos] = val
+        cases[name] = a
+    with_nan = base.copy()
+    with_nan[::5003] = np.nan
+    cases["ints_with_nan"] = with_nan
+    for name, a in cases.items():
+        s = np.sort(a)
+        vals, n_nan = ctx.order_stats(dev(ctx, a), ranks)
+        assert n_nan == int(np.isnan(a).sum()), name
+        assert np.array_equal(vals, s[ranks], equal_nan=True), name
+    planes = [cases["ints"], cases["fraction_late"], cases["ints_with_nan"]]       # a group with one general plane: all fall back
+    vals, nans = ctx.order_stats_multi([dev(ctx, p) for p in planes], [ranks] * 3)
+    for i, p in enumerate(planes):
+        assert np.array_equal(vals[i], np.sort(p)[ranks], equal_nan=True), i
+
+
 def test_band_percentiles_equal_numpy(ctx, scene, oracle):
     from rsseg.quantiles import band_percentiles, robust_scaler_stats
     bands = oracle.stage1_preprocess(scene["dn"])
