@@ -83,7 +83,7 @@ def family_table(cfg, F, glcm_step, k, n_pca):
 
 # dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
 PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7, 3>",
-              "select": "k1_hist<0, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>",
+              "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>",
               "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
 # static VALU instructions one wave executes per 64 windows in k4_glcm_thread<7,3> and their measured issue cost
 # (profiles/r02_valu_issue_microbench.md): the bound of the texture kernel is VALU issue, not HBM
