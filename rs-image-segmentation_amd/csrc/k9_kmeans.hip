@@ -881,10 +881,12 @@ int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plan
                   const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
 {
     if (update) {
-        static size_t attr = 48 * 1024;  // default dynamic-LDS limit without the attribute
-        if (lds > attr) {
+        static size_t attr[64] = {0};  // per device: the dynamic-LDS limit already granted to this instantiation
+        size_t &have = attr[ctx->device & 63];
+        if (have == 0) have = 48 * 1024;  // default limit without the attribute
+        if (lds > have) {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, FR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = lds;
+            have = lds;
         }
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
                            cenT, csq, labels, partial, nchunks, ncopies);
