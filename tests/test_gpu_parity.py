@@ -936,3 +936,30 @@ def test_raw_band_pca_and_fused_quantise_equal_two_step_forms(ctx, crop, oracle)
     assert torch.equal(one, two)
     with pytest.raises(ValueError):
         P.pca(ctx, bands, 3, True, lohi=lohi)  # raw bands need the precomputed RobustScaler statistics
+
+
+def test_normalise_division_is_the_ieee_quotient(ctx):
+    """robust_normalize's (clip(x) - lo) / (hi - lo + 1e-10) on the device: bit-equal to NumPy's float32 quotient for
+    ordinary, tiny, huge and degenerate ranges, and for numerators down to the denormals (no flush to zero, no
+    reciprocal shortcut)."""
+    rng = np.random.default_rng(11)
+    n = 1 << 18
+    f32 = np.float32
+    cases = [(0.0, 255.0), (3.0, 141.0), (-17.5, 90.25), (0.0, 1.0), (5.0, 5.0), (0.0, 1e-20), (0.0, 1e30), (-1e25, 1e25),
+             (0.0, float(np.nextafter(f32(2.0), f32(0.0)))),       # divisor with an all-ones significand
+             (0.0, 3e-19), (1e-3, 1.0000001e-3), (0.0, 8.6e18)]
+    for lo, hi in cases:
+        lo, hi = f32(lo), f32(hi)
+        span = float(hi) - float(lo)
+        x = np.concatenate([
+            (rng.random(n // 4) * span * 1.2 + float(lo) - 0.1 * span).astype(f32),            # across and beyond the range
+            (float(lo) + rng.random(n // 4) * span * rng.choice([1e-3, 1e-9, 1e-20, 1e-33, 1e-38], n // 4)).astype(f32),  # just above lo
+            rng.integers(0, 256, n // 4).astype(f32),                                            # DN values
+            np.frombuffer(rng.integers(0, 2**32, n // 4, dtype=np.uint32).tobytes(), f32),       # any bit pattern (NaN, inf, denormals)
+        ])
+        with np.errstate(all="ignore"):
+            want = (np.clip(x, lo, hi) - lo) / (hi - lo + f32(1e-10))
+        assert want.dtype == np.float32
+        got = ctx.normalize(dev(ctx, x), float(lo), float(hi)).cpu().numpy()
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (lo, hi, x[~same][:4], got[~same][:4], want[~same][:4])
