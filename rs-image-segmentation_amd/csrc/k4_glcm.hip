@@ -442,6 +442,315 @@ __global__ __launch_bounds__(256) void k4_glcm_thread(const uint8_t *__restrict_
     glcm_finish(g0, g1, NA, NB, r0, r1, r2, r3, (size_t)oy * ow + ox, out, gc);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k4_glcm_pair — the dense case (window 7, step 1, levels <= 32) with TWO horizontally adjacent windows per thread.
+// Windows x and x+1 share six of their seven columns: 35 of the 42 pair keys of the 0-degree angle, 36 of 42 (90),
+// 30 of 36 (45 and 135).  The shared keys are built and sorted ONCE; each window then sorts its own 7 (6) keys and
+// merges them into the shared run with Batcher's odd-even (m, n)-merging network (Knuth 5.3.4) before the same
+// run-length pass as k4_glcm_thread:   per window 404 compare-exchanges instead of 550, 46 packed keys built instead
+// of 78, 46 Hq table reads instead of 78.  The 7 x 8 patch of both windows fits the 14 registers the 7 x 7 window
+// already took.  Where an angle has one key fewer than its register partner (35 / 36, 6 / 7) the free half holds a
+// pad: an even value above every real key (no diagonal flag, equal to nothing), built from a pixel paired with
+// itself so that its table read adds exactly Hq(0) = 2^52, which is subtracted again.
+// Same integer statistics, same float64 finish: bit-identical to k4_glcm_thread (and to oracle.c mode 1).
+// ------------------------------------------------------------------------------------------------
+template <int M, int N> struct merge_net {
+    int a[(M + N) * 8], b[(M + N) * 8];
+    int n;
+    int order[M + N];  // register indices in ascending order of their values after the network
+};
+struct merge_emit {
+    int *a, *b, *n;
+};
+// merges the sorted runs held in registers x[0..m) and y[0..n): comparators appended to e, ascending order to out
+constexpr void oem_build(const int *x, int m, const int *y, int n, int *out, merge_emit e)
+{
+    if (m == 0) { for (int i = 0; i < n; i++) out[i] = y[i]; return; }
+    if (n == 0) { for (int i = 0; i < m; i++) out[i] = x[i]; return; }
+    if (m == 1 && n == 1) {
+        e.a[*e.n] = x[0]; e.b[*e.n] = y[0]; (*e.n)++;
+        out[0] = x[0]; out[1] = y[0];
+        return;
+    }
+    int xe[64] = {}, xo[64] = {}, ye[64] = {}, yo[64] = {}, v[128] = {}, w[128] = {};
+    int me = 0, mo = 0, ne = 0, no = 0;
+    for (int i = 0; i < m; i++) { if (i & 1) xo[mo++] = x[i]; else xe[me++] = x[i]; }
+    for (int i = 0; i < n; i++) { if (i & 1) yo[no++] = y[i]; else ye[ne++] = y[i]; }
+    oem_build(xe, me, ye, ne, v, e);
+    oem_build(xo, mo, yo, no, w, e);
+    const int lv = me + ne, lw = mo + no;
+    int k = 0;
+    out[k++] = v[0];
+    for (int i = 0; i < lw; i++) {
+        if (i + 1 < lv) {
+            e.a[*e.n] = w[i]; e.b[*e.n] = v[i + 1]; (*e.n)++;
+            out[k++] = w[i];
+            out[k++] = v[i + 1];
+        } else {
+            out[k++] = w[i];
+        }
+    }
+    for (int i = lw + 1; i < lv; i++) out[k++] = v[i];
+}
+template <int M, int N> constexpr merge_net<M, N> make_merge_net()
+{
+    merge_net<M, N> s{};
+    int x[M] = {}, y[N] = {};
+    for (int i = 0; i < M; i++) x[i] = i;
+    for (int i = 0; i < N; i++) y[i] = M + i;
+    int n = 0;
+    oem_build(x, M, y, N, s.order, merge_emit{s.a, s.b, &n});
+    s.n = n;
+    return s;
+}
+// zero-one principle restricted to merging: every pair of sorted 0/1 runs must come out sorted
+template <int M, int N> constexpr bool merge_net_ok(const merge_net<M, N> &s)
+{
+    for (int za = 0; za <= M; za++)
+        for (int zb = 0; zb <= N; zb++) {
+            int r[M + N] = {};
+            for (int i = 0; i < M; i++) r[i] = i >= za;
+            for (int i = 0; i < N; i++) r[M + i] = i >= zb;
+            for (int c = 0; c < s.n; c++) {
+                const int lo = r[s.a[c]] < r[s.b[c]] ? r[s.a[c]] : r[s.b[c]], hi = r[s.a[c]] + r[s.b[c]] - lo;
+                r[s.a[c]] = lo;
+                r[s.b[c]] = hi;
+            }
+            for (int i = 1; i < M + N; i++)
+                if (r[s.order[i - 1]] > r[s.order[i]]) return false;
+        }
+    return true;
+}
+template <int M, int N> struct merge_holder {
+    static constexpr merge_net<M, N> net = make_merge_net<M, N>();
+    static_assert(merge_net_ok(net), "odd-even merging network does not merge");
+};
+
+#define GP_PAD_LO 0x0000fffeu
+#define GP_PAD_HI 0xfffc0000u
+
+// pixel positions (patch row, patch column 0..7) of entry p of a key set: SET 0 = shared by both windows,
+// 1 = only window A (patch columns 0..6), 2 = only window B (columns 1..7).  half 0 = low 16 bits (angle 0 / 45 degrees),
+// half 1 = high 16 bits (90 / 135).  pad: the entry does not exist for this half.
+struct gp_pos {
+    int rx, cx, ry, cy;
+    bool pad;
+};
+template <int G, int SET> __host__ __device__ constexpr int gp_count() { return G == 0 ? (SET == 0 ? 36 : 7) : (SET == 0 ? 30 : 6); }
+template <int G, int SET> __host__ __device__ constexpr gp_pos gp_where(int p, int half)
+{
+    if (G == 0) {
+        if (half == 0) {  // 0 degrees: (r, c)-(r, c+1); pair columns 0 | 1..5 | 6
+            if (SET == 0) return p < 35 ? gp_pos{p / 5, 1 + p % 5, p / 5, 2 + p % 5, false} : gp_pos{0, 0, 0, 0, true};
+            return SET == 1 ? gp_pos{p, 0, p, 1, false} : gp_pos{p, 6, p, 7, false};
+        }
+        // 90 degrees: (r, c)-(r+1, c); columns 0 | 1..6 | 7
+        if (SET == 0) return gp_pos{p / 6, 1 + p % 6, p / 6 + 1, 1 + p % 6, false};
+        if (p >= 6) return gp_pos{0, 0, 0, 0, true};
+        return SET == 1 ? gp_pos{p, 0, p + 1, 0, false} : gp_pos{p, 7, p + 1, 7, false};
+    }
+    if (half == 0) {  // 45 degrees: (r, c)-(r+1, c+1); first columns 0 | 1..5 | 6
+        if (SET == 0) return gp_pos{p / 5, 1 + p % 5, p / 5 + 1, 2 + p % 5, false};
+        return SET == 1 ? gp_pos{p, 0, p + 1, 1, false} : gp_pos{p, 6, p + 1, 7, false};
+    }
+    // 135 degrees: (r, c)-(r+1, c-1); first columns 1 | 2..6 | 7
+    if (SET == 0) return gp_pos{p / 5, 2 + p % 5, p / 5 + 1, 1 + p % 5, false};
+    return SET == 1 ? gp_pos{p, 1, p + 1, 0, false} : gp_pos{p, 7, p + 1, 6, false};
+}
+template <int G, int SET> __host__ __device__ constexpr int gp_pads()
+{
+    int n = 0;
+    for (int p = 0; p < gp_count<G, SET>(); p++) n += (gp_where<G, SET>(p, 0).pad ? 1 : 0) + (gp_where<G, SET>(p, 1).pad ? 1 : 0);
+    return n;
+}
+
+// builds the packed keys of one set into K[OFF ..) and returns the sum of their Hq table reads (pads included)
+template <int G, int SET, int OFF, int NK>
+__device__ __forceinline__ long long gp_build(const unsigned (&P)[8][2], const long long *__restrict__ hq, unsigned (&K)[NK])
+{
+    long long Hq = 0;
+    static_for<gp_count<G, SET>()>([&](auto I) {
+        constexpr int p = I;
+        constexpr gp_pos A = gp_where<G, SET>(p, 0), B = gp_where<G, SET>(p, 1);
+        constexpr unsigned selx = (unsigned)(A.cx & 3) | (0x0cu << 8) | ((unsigned)(4 + (B.cx & 3)) << 16) | (0x0cu << 24);
+        constexpr unsigned sely = (unsigned)(A.cy & 3) | (0x0cu << 8) | ((unsigned)(4 + (B.cy & 3)) << 16) | (0x0cu << 24);
+        const unsigned x = __builtin_amdgcn_perm(P[B.rx][B.cx >> 2], P[A.rx][A.cx >> 2], selx);
+        const unsigned y = __builtin_amdgcn_perm(P[B.ry][B.cy >> 2], P[A.ry][A.cy >> 2], sely);
+        const unsigned lo = pk_min(x, y), hi = pk_max(x, y);
+        const unsigned d = pk_sub(hi, lo);
+        const unsigned one = 0x00010001u;
+        const unsigned diag = pk_sub_sat(one, d);
+        unsigned k = ((lo << 8) | hi) | diag;
+        if constexpr (A.pad) k = (k & 0xffff0000u) | GP_PAD_LO;
+        if constexpr (B.pad) k = (k & 0x0000ffffu) | GP_PAD_HI;
+        K[OFF + p] = k;
+        pin32(K[OFF + p]);
+        const unsigned off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, d), (us2){1, 32}, 0u, false);
+        Hq += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq) + off);
+        if constexpr (p % 6 == 5) pin64(Hq);
+    });
+    return Hq;
+}
+
+// E2 and D (both halves packed) of the keys in K taken in the order ORD
+template <int NK, typename NET> __device__ __forceinline__ void gp_runlength(const unsigned (&K)[NK], unsigned &E2, unsigned &D)
+{
+    const unsigned one = 0x00010001u;
+    E2 = 0;
+    unsigned t = 0;
+    D = K[NET::net.order[0]] & one;
+    static_for<NK - 1>([&](auto I) {
+        constexpr int i = NET::net.order[I + 1], j = NET::net.order[I];
+        const unsigned diag = K[i] & one;
+        const unsigned ne = pk_min_opaque(K[i] ^ K[j], one);
+        const unsigned keep = pk_sub(ne, one);
+        t = (t + one + diag) & keep;
+        E2 += t;
+        D += diag;
+    });
+}
+
+template <int NS> __device__ __forceinline__ void opaque_patch(unsigned (&P)[8][2])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_for<NS>([&](auto I) {
+        unsigned &a = P[I][0];
+        unsigned &b = P[I][1];
+        asm volatile("" : "+v"(a), "+v"(b));
+    });
+#endif
+}
+
+// one angle group of both windows: E2 / D per window from the shared sorted run, Hq per window
+template <int G>
+__device__ __forceinline__ void gp_group(const unsigned (&P)[8][2], const long long *__restrict__ hq, long long &HqA, long long &HqB,
+                                         double &sqA, double &sqB)
+{
+    constexpr int NS = gp_count<G, 0>(), NO = gp_count<G, 1>(), NK = NS + NO;
+    constexpr int PAIRS = G == 0 ? 42 : 36;
+    using MNET = merge_holder<NS, NO>;
+    unsigned KA[NK], KB[NK];
+    const long long HqS = gp_build<G, 0, 0, NK>(P, hq, KA);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<net_holder<NS>::net.n>([&](auto I) {
+        constexpr int ia = net_holder<NS>::net.a[I], ib = net_holder<NS>::net.b[I];
+        const unsigned ka = KA[ia], kb = KA[ib];
+        KA[ia] = pk_min(ka, kb);
+        KA[ib] = pk_max(ka, kb);
+    });
+    static_for<NS>([&](auto I) { KB[I] = KA[I]; });
+    __builtin_amdgcn_sched_barrier(0);
+    auto window = [&](auto set_t, unsigned (&K)[NK], long long &Hq, double &sq) {
+        constexpr int SET = decltype(set_t)::value;
+        Hq = HqS + gp_build<G, SET, NS, NK>(P, hq, K) - (long long)(gp_pads<G, 0>() + gp_pads<G, SET>()) * 4503599627370496ll;
+        static_for<net_holder<NO>::net.n>([&](auto I) {
+            constexpr int ia = NS + net_holder<NO>::net.a[I], ib = NS + net_holder<NO>::net.b[I];
+            const unsigned ka = K[ia], kb = K[ib];
+            K[ia] = pk_min(ka, kb);
+            K[ib] = pk_max(ka, kb);
+        });
+        static_for<MNET::net.n>([&](auto I) {
+            constexpr int ia = MNET::net.a[I], ib = MNET::net.b[I];
+            const unsigned ka = K[ia], kb = K[ib];
+            K[ia] = pk_min(ka, kb);
+            K[ib] = pk_max(ka, kb);
+        });
+        unsigned E2, D;
+        gp_runlength<NK, MNET>(K, E2, D);
+        const long long Aa = 2ll * (PAIRS + (int)(D & 0xffffu)) + 4ll * (long long)(E2 & 0xffffu);
+        const long long Ab = 2ll * (PAIRS + (int)(D >> 16)) + 4ll * (long long)(E2 >> 16);
+        sq = sqrt((double)Aa) + sqrt((double)Ab);
+    };
+    window(std::integral_constant<int, 1>{}, KA, HqA, sqA);
+    __builtin_amdgcn_sched_barrier(0);
+    window(std::integral_constant<int, 2>{}, KB, HqB, sqB);
+}
+
+// everything of one window that does not involve the key sort: pair moments, M1 / M2, the float64 finish
+__device__ __forceinline__ void gp_finish(unsigned (&w)[8][2], long long Hq0, double sq0, long long Hq1, double sq1, size_t o,
+                                          const glcm_out &out, const glcm_consts &gc)
+{
+    constexpr int WIN = 7, SH = 3;
+    unsigned S1a, XYa, S1b, XYb, S1c, XYc, S1d, XYd;
+    row_moments<WIN, 0, 1>(w, S1a, XYa);
+    row_moments<WIN, 1, 0>(w, S1b, XYb);
+    row_moments<WIN, 1, 1>(w, S1c, XYc);
+    row_moments<WIN, 1, -1>(w, S1d, XYd);
+    unsigned m1[4], m2[4];
+    window_m1m2<WIN>(w, m1, m2);
+    constexpr long long NA = (long long)WIN * (WIN - 1), NB = (long long)(WIN - 1) * (WIN - 1);
+    const long long xy0 = XYa >> (2 * SH), xy90 = XYb >> (2 * SH), xy45 = XYc >> (2 * SH), xy135 = XYd >> (2 * SH);
+    const long long M20 = m2[0] >> (2 * SH), M245 = m2[1] >> (2 * SH), M290 = m2[2] >> (2 * SH), M2135 = m2[3] >> (2 * SH);
+    glcm_group g0, g1;
+    g0.S1 = (S1a + S1b) >> SH;
+    g0.S2 = (M20 - 2ll * xy0) + (M290 - 2ll * xy90);
+    g0.Hq = Hq0;
+    g0.sq = sq0;
+    g1.S1 = (S1c + S1d) >> SH;
+    g1.S2 = (M245 - 2ll * xy45) + (M2135 - 2ll * xy135);
+    g1.Hq = Hq1;
+    g1.sq = sq1;
+    const double r0 = glcm_corr(NA, m1[0] >> SH, M20, 2ll * xy0), r1 = glcm_corr(NB, m1[1] >> SH, M245, 2ll * xy45);
+    const double r2 = glcm_corr(NA, m1[2] >> SH, M290, 2ll * xy90), r3 = glcm_corr(NB, m1[3] >> SH, M2135, 2ll * xy135);
+    glcm_finish(g0, g1, NA, NB, r0, r1, r2, r3, o, out, gc);
+}
+
+__global__ __launch_bounds__(256) void k4_glcm_pair(const uint8_t *__restrict__ q, int H, int W, int oh, int ow, glcm_out out,
+                                                    glcm_consts gc)
+{
+    constexpr int SH = 3;
+    __shared__ long long hq[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) hq[i] = g_glcm_hq2[i];
+    __syncthreads();
+    const int ox = 2 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const bool hasB = ox + 1 < ow;  // an odd map width leaves the last thread of a row with one window
+    unsigned P[8][2];
+    {
+        const uint8_t *wp = q + (size_t)oy * W + (size_t)ox;
+        static_for<7>([&](auto I) {
+            constexpr int r = I;
+            unsigned lo = 0, hi = 0;
+            static_for<8>([&](auto J) {
+                constexpr int c = J;
+                const unsigned b = (c < 7 || hasB) ? wp[(size_t)r * W + c] : 0u;
+                if constexpr (c < 4) lo |= b << (8 * c + SH);
+                else hi |= b << (8 * (c - 4) + SH);
+            });
+            P[r][0] = lo;
+            P[r][1] = hi;
+        });
+        P[7][0] = P[7][1] = 0;
+    }
+    long long Hq[2][2];
+    double sq[2][2];
+#pragma nounroll
+    for (int g = 0; g < 2; g++) {
+        opaque_patch<7>(P);
+        if (g == 0) gp_group<0>(P, hq, Hq[0][0], Hq[1][0], sq[0][0], sq[1][0]);
+        else gp_group<1>(P, hq, Hq[0][1], Hq[1][1], sq[0][1], sq[1][1]);
+    }
+    const size_t o = (size_t)oy * ow + ox;
+    unsigned w[8][2];
+    opaque_patch<7>(P);
+    static_for<7>([&](auto I) {
+        w[I][0] = P[I][0];
+        w[I][1] = P[I][1] & 0x00ffffffu;
+    });
+    w[7][0] = w[7][1] = 0;
+    gp_finish(w, Hq[0][0], sq[0][0], Hq[0][1], sq[0][1], o, out, gc);
+    if (hasB) {
+        opaque_patch<7>(P);
+        static_for<7>([&](auto I) {
+            w[I][0] = __builtin_amdgcn_alignbyte(P[I][1], P[I][0], 1);
+            w[I][1] = P[I][1] >> 8;
+        });
+        gp_finish(w, Hq[1][0], sq[1][0], Hq[1][1], sq[1][1], o + 1, out, gc);
+    }
+}
+
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
 // One WAVE per window (levels <= 32, any window size < 256): the four angles' co-occurrence counts live in four private
 // 2 KB LDS tables of packed 16-bit counters (a window has fewer than 65536 pairs); no workgroup barrier anywhere — a wave's
@@ -602,7 +911,10 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         if (levels <= 32) hipLaunchKernelGGL((k4_glcm_thread<WN, 3>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc); \
         else hipLaunchKernelGGL((k4_glcm_thread<WN, 2>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc);          \
     } while (0)
-        if (win == 7) GLCM_THREAD(7);
+        if (win == 7 && step == 1 && levels <= 32) {
+            const dim3 pg((ow + 127) / 128, (oh + 3) / 4);   // two adjacent windows per thread
+            hipLaunchKernelGGL(k4_glcm_pair, pg, dim3(256), 0, ctx->stream, d_q, H, W, oh, ow, out, gc);
+        } else if (win == 7) GLCM_THREAD(7);
         else if (win == 5) GLCM_THREAD(5);
         else if (win == 3) GLCM_THREAD(3);
         else {
