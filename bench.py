@@ -82,12 +82,13 @@ def family_table(cfg, F, glcm_step, k, n_pca):
 
 
 # dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
-PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_thread<7, 3>",
+PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_pair",
               "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>",
               "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
-# static VALU instructions one wave executes per 64 windows in k4_glcm_thread<7,3> and their measured issue cost
-# (profiles/r02_valu_issue_microbench.md): the bound of the texture kernel is VALU issue, not HBM
-GLCM_VALU = {"insts_per_wave": 2996, "issue_cycles_per_wave": None}
+# static VALU instructions of the texture kernels and their measured issue cost (profiles/valu_mix.py ->
+# profiles/r02_valu_issue.json): the bound of the texture kernel is VALU issue, not HBM.  Dense case (window 7, step 1):
+# k4_glcm_pair, 128 windows per wave; other steps: k4_glcm_thread<7,3>, 64 windows per wave.
+GLCM_VALU = {"insts_per_wave": 2954, "issue_cycles_per_wave": None}
 
 
 def pmc_traffic_bytes(family, px):
@@ -107,13 +108,16 @@ def pmc_traffic_bytes(family, px):
     return None
 
 
-def glcm_issue_cycles():
-    """Weighted VALU issue cycles per window-wave from the committed microbenchmark summary, if present."""
+def glcm_issue_cycles(glcm_step=1):
+    """(weighted VALU issue cycles per wave, windows per wave, static VALU instructions per wave, kernel) of the texture
+    kernel that runs at this step, from the committed microbenchmark summary; cycles None when it is absent."""
+    key, kern = ("glcm_pair", "k4_glcm_pair") if glcm_step == 1 else ("glcm_thread_7_3", "k4_glcm_thread<7,3>")
     f = os.path.join(ROOT, "profiles", "r02_valu_issue.json")
     try:
-        return json.load(open(f))["glcm_thread_7_3"]["issue_cycles_per_wave"]
+        e = json.load(open(f))[key]
+        return e["issue_cycles_per_wave"], 64 * e["windows_per_thread"], e["valu_static"], kern
     except Exception:  # noqa: BLE001
-        return None
+        return None, 64, GLCM_VALU["insts_per_wave"], kern
 
 
 # ---- CPU baseline (rank 0, N = 1) -------------------------------------------------------------------------------------
@@ -308,14 +312,16 @@ def main():
             elif bound == "valu" and cfg != "c3":
                 ent["frac"] = None      # window 21 / step 21 runs the workgroup-per-window kernel: no instruction model for it
             elif bound == "valu":
-                cyc = glcm_issue_cycles()
-                waves = px / 64.0
+                cyc, win_per_wave, insts, kern = glcm_issue_cycles(args.glcm_step)
+                waves = px / float(win_per_wave)
                 if cyc is not None:
                     ent["frac"] = round(waves * cyc / (N_SIMD * CLOCK_HZ * per_launch_s), 4)
                     ent["valu_issue_cycles_per_wave"] = cyc
-                else:  # nominal 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md) until the microbenchmark is committed
-                    ent["frac"] = round(waves * GLCM_VALU["insts_per_wave"] * 2 / (N_SIMD * CLOCK_HZ * per_launch_s), 4)
-                ent["valu_insts_per_wave"] = GLCM_VALU["insts_per_wave"]
+                else:  # nominal 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md) when the summary is missing
+                    ent["frac"] = round(waves * insts * 2 / (N_SIMD * CLOCK_HZ * per_launch_s), 4)
+                ent["valu_insts_per_wave"] = insts
+                ent["windows_per_wave"] = win_per_wave
+                ent["kernel"] = kern
             elif bound == "latency" and visits:
                 ent["node_visits_per_px"] = round(visits, 1)
                 ent["node_visits_per_s"] = round(px * visits / per_launch_s, 0)

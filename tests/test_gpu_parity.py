@@ -261,9 +261,23 @@ def test_glcm_other_level_counts_bitexact_vs_oracle(ctx, oracle, levels, win, st
         assert np.array_equal(host(g, (oh, ow)), want[k]), (k, levels, win, step)
 
 
-def test_glcm_dense_sliding_kernel_bitexact_vs_oracle(ctx, oracle):
-    """Dense 7x7 / step 1 / 32 levels on a map wider than one strip (128 columns) and taller than one wave (64 rows,
-    last wave partial): the sliding-window kernel against the oracle, all five properties bit for bit."""
+def test_glcm_dense_pair_kernel_edge_maps(ctx, oracle):
+    """Dense 7x7 / step 1 / 32 levels runs k4_glcm_pair (two adjacent windows per thread): maps of width 1, 2, 3 (a thread
+    with one window only), exactly one workgroup strip (128), one strip + 1 and + 2, single rows."""
+    rng = np.random.default_rng(5)
+    for H, W in ((7, 7), (7, 8), (8, 9), (9, 134), (7, 135), (12, 136), (11, 20)):
+        q = rng.integers(0, 32, (H, W)).astype(np.uint8)
+        q[:, : W // 2] = (q[:, : W // 2] // 8) * 8   # few distinct levels on the left: many equal keys
+        want = oracle.glcm_small_maps(q, 32, 7, 1, mode=1)
+        got, (oh, ow) = ctx.glcm(dev(ctx, q), H, W, 32, 7, 1)
+        assert (oh, ow) == (H - 6, W - 6)
+        for g, k in zip(got, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
+            assert np.array_equal(host(g, (oh, ow)), want[k]), (k, H, W)
+
+
+def test_glcm_dense_pair_kernel_bitexact_vs_oracle(ctx, oracle):
+    """Dense 7x7 / step 1 / 32 levels on a map wider than one workgroup strip (128 windows) and taller than one
+    workgroup (4 rows): k4_glcm_pair against the oracle, all five properties bit for bit."""
     rng = np.random.default_rng(77)
     H, W = 150, 300
     base = rng.integers(0, 32, (H, W))
