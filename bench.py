@@ -345,7 +345,7 @@ def main():
         out = {
             "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (scene + ", robust-normalise + 7 spectral indices"
                                     + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if cfg == "c3" else "")
                                     + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if cfg != "c5" else

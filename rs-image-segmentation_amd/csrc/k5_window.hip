@@ -418,8 +418,12 @@ __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int s
     const float *__restrict__ src = pl.src[plane];
     float *__restrict__ dst = pl.dst[plane];
     float mn = INFINITY, mx = -INFINITY;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int px = (int)(tile % gx) * WG_X + (threadIdx.x & 63), pyl = (int)(tile / gx) * WG_Y + (threadIdx.x >> 6);
+    // tile (tx, ty) of the row-major tile grid, advanced by gridDim.x tiles per iteration without a division per pixel
+    const int step_y = (int)(gridDim.x / (unsigned)gx), step_x = (int)(gridDim.x % (unsigned)gx);
+    int tx = (int)(blockIdx.x % (unsigned)gx), ty = (int)(blockIdx.x / (unsigned)gx);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, tx += step_x, ty += step_y) {
+        if (tx >= gx) { tx -= gx; ty++; }
+        const int px = tx * WG_X + (threadIdx.x & 63), pyl = ty * WG_Y + (threadIdx.x >> 6);
         if (px < dw && pyl < dh_local) {
             const float v = resize_px(src, sh, sw, scale_x, scale_y, src_row0, px, pyl + dst_row0);
             dst[(size_t)pyl * dw + px] = v;
