@@ -104,6 +104,28 @@ class Context:
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
 
+    def install_comm_hook(self, rank: int, world: int, hook):
+        """A caller-supplied all-reduce instead of torch.distributed: hook(buf, offset, count, dtype, op) -> None reduces
+        `count` elements of `dtype` (rsseg._lib F32 / F64 / I64) at byte `offset` of the uint8 device tensor `buf` in place
+        across the caller's ranks, ordered after the work on this context's stream (rsseg_allreduce_fn's contract).  Used
+        by the test-suite to run many ranks as threads of one process on one GPU."""
+        torch = _torch()
+        self.rank, self.world = int(rank), int(world)
+        self._comm_buf = torch.zeros(1 << 22, dtype=torch.uint8, device=self.device)
+        buf = self._comm_buf
+
+        def cb(_user, offset, count, dtype, op):
+            try:
+                hook(buf, offset, count, dtype, op)
+                return 0
+            except Exception as e:  # noqa: BLE001 — must not propagate through the C frame
+                print(f"[rsseg] all-reduce hook failed: {e!r}", flush=True)
+                return 1
+
+        self._hook = L.ALLREDUCE_FN(cb)
+        self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
+                                              C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
+
     def set_async(self, on: bool = True):
         """Asynchronous entry points.  Buffers handed out by empty() are then kept alive until sync(): the
         caching allocator would otherwise recycle a temporary the moment Python drops it, while kernels that

@@ -177,3 +177,108 @@ def test_window_ops_rows_form_equals_full_plane(ctx):
     multi = ctx.box_mean_multi(ps, H, W, 7, L.BORDER_REFLECT)
     for p, m in zip(ps, multi):
         assert np.array_equal(m.cpu().numpy(), ctx.box_mean(p, H, W, 7, L.BORDER_REFLECT).cpu().numpy())
+
+
+class _ThreadWorld:
+    """N ranks as N threads of this process on one GPU: the library's all-reduce hook of every rank meets at a barrier,
+    rank 0 reduces the N device buffers, every rank copies the result back.  Lets the suite run the 8-way split the
+    8-GPU bench uses without 8 processes on the card."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=120)
+        self.slots = [None] * world
+        self.result = None
+        self.calls = 0
+
+    def hook(self, rank):
+        import torch
+        from rsseg import _lib as L
+        views = {L.F32: torch.float32, L.F64: torch.float64, L.I64: torch.int64}
+
+        def fn(buf, offset, count, dtype, op):
+            esz = 4 if dtype == L.F32 else 8
+            t = buf[offset:offset + count * esz].view(views[dtype])
+            torch.cuda.synchronize()
+            self.slots[rank] = t
+            self.bar.wait()
+            if rank == 0:
+                st = torch.stack(self.slots)
+                self.result = st.sum(0) if op == L.SUM else (st.amin(0) if op == L.MIN else st.amax(0))
+                self.calls += 1
+                torch.cuda.synchronize()
+            self.bar.wait()
+            t.copy_(self.result)
+            torch.cuda.synchronize()
+            self.bar.wait()
+
+        return fn
+
+    def run(self, target):
+        """target(rank) in one thread per rank; re-raises the first failure (the barrier is aborted so nobody hangs)."""
+        import threading
+        errs = []
+
+        def wrap(r):
+            try:
+                target(r)
+            except BaseException as e:  # noqa: BLE001
+                errs.append((r, e))
+                self.bar.abort()
+
+        th = [threading.Thread(target=wrap, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert not any(t.is_alive() for t in th), "a rank thread did not finish"
+        if errs:
+            raise AssertionError(f"rank {errs[0][0]} failed: {errs[0][1]!r}")
+
+
+@pytest.mark.parametrize("world", [8, 5])
+def test_many_stripes_in_threads_equal_single_gpu(ctx, oracle, world):
+    """The 8-way row split of the multi-GPU bench (and an uneven 5-way one), every rank a thread with its own context:
+    config 3 (texture halos) and the 19-feature stack of config 5 (3 / 2 / 1-row and window-aligned halos), labels and
+    planes of every stripe against the rows of the single-context result, bit for bit."""
+    import torch
+    from rsseg import pipeline as P
+    from rsseg.runtime import Context
+    H, W, k = 203, 136, 8
+    bands = oracle.synthetic_raster(H, W)
+    dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(7)]
+    labels, meta, planes = P.config3(ctx, dev, H, W, k, 7, 1, 3)
+    want_labels = labels.cpu().numpy()
+    want_planes = [p.cpu().numpy() for p in planes]
+    s19, _ = P.feature_stack19(ctx, dev, H, W)
+    want19 = [p.cpu().numpy() for p in s19]
+    tw = _ThreadWorld(world)
+    out = [None] * world
+
+    def rank_main(r):
+        c = Context(0, use_dist=False)
+        c.install_comm_hook(r, world, tw.hook(r))
+        r0, r1 = P.stripe_rows(H, world, r)
+        j0, j1, i0, i1 = P.glcm_halo_rows(H, r0, r1, 7, 1)
+        d = [c.to_device(bands[i, r0:r1].reshape(-1)) for i in range(7)]
+        nir_ext = c.to_device(bands[3, i0:i1].reshape(-1))
+        lab, m, pl = P.config3_striped(c, d, nir_ext, H, W, r0, r1, i0, k)
+        e0, e1 = P.stack19_halo_rows(H, r0, r1)
+        ext = [c.to_device(bands[i, e0:e1].reshape(-1)) for i in range(7)]
+        p19, _ = P.stack19_striped(c, ext, H, W, r0, r1, e0)
+        torch.cuda.synchronize()
+        out[r] = (r0, r1, lab.cpu().numpy(), m["n_iter"], [p.cpu().numpy() for p in pl], [p.cpu().numpy() for p in p19])
+        c.close()
+
+    tw.run(rank_main)
+    assert tw.calls > 10
+    for r in range(world):
+        r0, r1, lab, n_iter, pl, p19 = out[r]
+        a, b = r0 * W, r1 * W
+        assert n_iter == meta["n_iter"], r
+        assert np.array_equal(lab, want_labels[a:b]), r
+        for i, p in enumerate(pl):
+            assert np.array_equal(p, want_planes[i][a:b], equal_nan=True), (r, i)
+        for i, p in enumerate(p19):
+            assert np.array_equal(p, want19[i][a:b], equal_nan=True), (r, i)
