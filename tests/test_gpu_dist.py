@@ -282,3 +282,47 @@ def test_many_stripes_in_threads_equal_single_gpu(ctx, oracle, world):
             assert np.array_equal(p, want_planes[i][a:b], equal_nan=True), (r, i)
         for i, p in enumerate(p19):
             assert np.array_equal(p, want19[i][a:b], equal_nan=True), (r, i)
+
+
+def test_full_size_eight_stripes_in_threads_equal_single_gpu(ctx):
+    """BASELINE configs[3] at its real size: the 16384 x 16384 x 7 raster split into 8 stripes of 2048 rows (what
+    `bench.py --gpus 8` gives every GPU), each stripe a thread with its own context on this one GPU.  Labels, iteration
+    count and the texture / component planes of every stripe equal the rows of the single-context run bit for bit —
+    stripe offsets beyond 2^31 bytes, 2048 k-means chunks per rank, 8-rank prefix logic of the k-means++ sampling."""
+    import torch
+    from rsseg import pipeline as P
+    from rsseg.runtime import Context
+    H = W = 16384
+    world, k = 8, 8
+    yy = torch.arange(H, device=ctx.device, dtype=torch.int32)[:, None]
+    xx = torch.arange(W, device=ctx.device, dtype=torch.int32)[None, :]
+    bands = []
+    for b in range(7):
+        v = (yy * (3 + b) + xx * (5 + 2 * b) + (yy >> 5) * (xx >> 6) * 7 + ((yy * xx) >> 9) + b * 31) % 256
+        bands.append(v.to(torch.float32).reshape(-1).contiguous())
+        del v
+    labels, meta, planes = P.config3(ctx, bands, H, W, k, 7, 1, 3, H * W)
+    torch.cuda.synchronize()
+    keep = [planes[7], planes[11], planes[14]]
+    del planes
+    tw = _ThreadWorld(world)
+    ok = [None] * world
+
+    def rank_main(r):
+        c = Context(0, use_dist=False)
+        c.install_comm_hook(r, world, tw.hook(r))
+        r0, r1 = P.stripe_rows(H, world, r)
+        j0, j1, i0, i1 = P.glcm_halo_rows(H, r0, r1, 7, 1)
+        d = [b[r0 * W:r1 * W] for b in bands]
+        nir_ext = bands[3][i0 * W:i1 * W]
+        lab, m, pl = P.config3_striped(c, d, nir_ext, H, W, r0, r1, i0, k)
+        torch.cuda.synchronize()
+        a, e = r0 * W, r1 * W
+        ok[r] = (m["n_iter"] == meta["n_iter"], bool(torch.equal(lab, labels[a:e])),
+                 [bool(torch.equal(pl[i], kp[a:e])) for i, kp in zip((7, 11, 14), keep)])
+        del lab, pl
+        c.close()
+
+    tw.run(rank_main)
+    for r in range(world):
+        assert ok[r] is not None and ok[r][0] and ok[r][1] and all(ok[r][2]), (r, ok[r])
