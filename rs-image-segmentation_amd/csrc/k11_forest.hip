@@ -39,8 +39,13 @@ struct __align__(8) rf_node {
     float thr;
     unsigned bits;
 };
-#define RF_LEAF 0x80000000u
-#define RF_MISS 0x40000000u
+// bits: [0,22) index of the left child within the tree (right = left + 1; a leaf: its own index), bit 22 missing-goes-
+// left, bit 23 leaf, byte 3 = 4 * feature (0 on a leaf).  Byte 3 is a clean byte offset into a pixel's feature row, so
+// the walk forms the feature address with ONE instruction (v_add_u32 with a byte-3 operand select) instead of
+// shift + mask + add, and the child index needs one mask.
+#define RF_LEAF 0x00800000u
+#define RF_MISS 0x00400000u
+#define RF_CHILD 0x003fffffu
 #define RF_NAN_BITS 0x7fc00000u   // leaf thr: quiet NaN | payload
 #define RF_PAY_MASK 0x003fffffu   // payload: row of the vote table
 
@@ -124,17 +129,18 @@ __device__ __forceinline__ int rf_stage_features(const rf_planes &pl, int F, int
 #define RF_NCH (RF_PX * RF_C)
 
 template <bool NANS>
-__device__ __forceinline__ void rf_round_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C])
+__device__ __forceinline__ void rf_round_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, unsigned px_stride, const unsigned (&base)[RF_C])
 {
+    // feat_tid: LDS address of the thread's first pixel's feature row ([pixel][FP] floats, FP odd: conflict-free fills)
     float x[RF_NCH];
 #pragma unroll
     for (int q = 0; q < RF_NCH; q++)   // chain q: pixel q / RF_C of the thread, tree q % RF_C of the group
-        x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * (RF_LT * 4) + ((nd[q].bits >> 24) & 63u) * (RF_TH * 4));
+        x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * px_stride + (nd[q].bits >> 24));
 #pragma unroll
     for (int q = 0; q < RF_NCH; q++) {
         bool go_right = x[q] > nd[q].thr;
         if (NANS) go_right = go_right || (x[q] != x[q] && !(nd[q].bits & RF_MISS));
-        const unsigned next = (nd[q].bits & 0xffffffu) + (go_right ? 1u : 0u);
+        const unsigned next = (nd[q].bits & RF_CHILD) + (go_right ? 1u : 0u);
         lds_cnode *p = (lds_cnode *)(base[q % RF_C] + next * 8u);
         nd[q].thr = p->thr;
         nd[q].bits = p->bits;
@@ -145,15 +151,15 @@ __device__ __forceinline__ void rf_round_lds(rf_node (&nd)[RF_NCH], unsigned fea
 // SECOND round: one test costs as much as a chain step, and a lane that reaches its last leaf after an odd number of
 // rounds merely repeats it once.  Shallow forests (the reference's bundled model: depth <= 5) keep the test every round.
 template <bool NANS>
-__device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, const unsigned (&base)[RF_C], bool two)
+__device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat_tid, unsigned px_stride, const unsigned (&base)[RF_C], bool two)
 {
     for (;;) {
         unsigned all = nd[0].bits;
 #pragma unroll
         for (int q = 1; q < RF_NCH; q++) all &= nd[q].bits;
         if (all & RF_LEAF) break;
-        rf_round_lds<NANS>(nd, feat_tid, base);
-        if (two) rf_round_lds<NANS>(nd, feat_tid, base);
+        rf_round_lds<NANS>(nd, feat_tid, px_stride, base);
+        if (two) rf_round_lds<NANS>(nd, feat_tid, px_stride, base);
     }
 }
 
@@ -167,8 +173,9 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
                                                         int n_classes, const long long *__restrict__ classes, long long *__restrict__ out)
 {
     extern __shared__ __align__(16) char smem[];
-    float *feat = reinterpret_cast<float *>(smem);                             // [F][RF_TH]
-    uint4 *top = reinterpret_cast<uint4 *>(feat + (size_t)F * RF_TH);          // the current group's nodes, two per uint4
+    const int FP = F | 1;                                                      // odd row length: the fills below hit 64 distinct banks
+    float *feat = reinterpret_cast<float *>(smem);                             // [RF_TH pixels][FP]
+    uint4 *top = reinterpret_cast<uint4 *>(feat + (size_t)FP * RF_TH);         // the current group's nodes, two per uint4
     const int64_t i0 = (int64_t)blockIdx.x * RF_TH + threadIdx.x;             // pixel p of the thread: i0 + p * RF_LT
     int my_nan = 0;
     for (int f = 0; f < F; f++)
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
             const int64_t i = i0 + p * RF_LT;
             const float v = i < n ? pl.p[f][i] : 0.f;
             my_nan |= v != v;
-            feat[f * RF_TH + p * RF_LT + threadIdx.x] = v;
+            feat[(p * RF_LT + threadIdx.x) * FP + f] = v;
         }
     {
         const rf_group g0 = groups[0];
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
         if (threadIdx.x == 0) top[cap2] = make_uint4(RF_NAN_BITS, RF_LEAF | RF_MISS, RF_NAN_BITS, RF_LEAF | RF_MISS);
     }
     const bool any_nan = __syncthreads_or(my_nan) != 0;  // workgroup-uniform; also the barrier behind the fills above
-    const unsigned feat_tid = (unsigned)(uintptr_t)(lds_cfloat *)feat + threadIdx.x * 4u;
+    const unsigned feat_tid = (unsigned)(uintptr_t)(lds_cfloat *)feat + threadIdx.x * (unsigned)FP * 4u;
+    const unsigned px_stride = (unsigned)RF_LT * (unsigned)FP * 4u;
     const unsigned top_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const uint4 *)top;
     double acc[RF_PX][NC];
 #pragma unroll
@@ -221,8 +229,8 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
                 nd[px * RF_C + c].bits = p->bits;
             }
         }
-        if (any_nan) rf_walk_lds<true>(nd, feat_tid, base, two_rounds != 0);
-        else rf_walk_lds<false>(nd, feat_tid, base, two_rounds != 0);
+        if (any_nan) rf_walk_lds<true>(nd, feat_tid, px_stride, base, two_rounds != 0);
+        else rf_walk_lds<false>(nd, feat_tid, px_stride, base, two_rounds != 0);
         // refill first (frees the prefetch registers: holding them AND the vote rows spilled 96 bytes per lane to scratch
         // memory, 800 B/px of extra HBM writes), then request the vote rows of all chains at once; the second barrier and
         // the next group's set-up cover most of the gather latency, and the rows are added in tree order behind it
@@ -274,9 +282,9 @@ __device__ __forceinline__ void rf_walk_gen(rf_node (&nd)[RF_C], lds_cfloat *fea
         unsigned leafm[RF_C];  // all ones when the chain sits on its leaf (bit 31 of the node), as a mask: no control flow
 #pragma unroll
         for (int c = 0; c < RF_C; c++) {
-            leafm[c] = (unsigned)((int)nd[c].bits >> 31);
-            const unsigned f = (nd[c].bits >> 24) & 63u & ~leafm[c];
-            x[c] = feat[f * RF_TH + threadIdx.x];
+            leafm[c] = (unsigned)((int)(nd[c].bits << 8) >> 31);
+            const unsigned f4 = nd[c].bits >> 24;          // 4 * feature; 0 on a leaf
+            x[c] = feat[f4 * (RF_TH / 4) + threadIdx.x];
         }
         unsigned next[RF_C], out[RF_C];
         rf_node ld[RF_C];
@@ -284,7 +292,7 @@ __device__ __forceinline__ void rf_walk_gen(rf_node (&nd)[RF_C], lds_cfloat *fea
         for (int c = 0; c < RF_C; c++) {
             bool go_right = x[c] > nd[c].thr;
             if (NANS) go_right = go_right || (x[c] != x[c] && !(nd[c].bits & RF_MISS));
-            next[c] = (nd[c].bits & 0xffffffu) + (go_right ? 1u : 0u);
+            next[c] = (nd[c].bits & RF_CHILD) + (go_right ? 1u : 0u);
             out[c] = ((int)next[c] >= lim[c] ? 0xffffffffu : 0u) & ~leafm[c];
             const unsigned a = next[c] & ~(leafm[c] | out[c]);
             lds_cnode *p = top + c * ntop + a;
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int
 // nodes of a tree group that fit the LDS beside the features of 1024 pixels (one 16-byte piece is kept for the dummy leaf)
 static int rf_lds_cap(int F)
 {
-    const long bytes = 160L * 1024 - 256 - (long)F * RF_TH * 4 - 16;
+    const long bytes = 160L * 1024 - 256 - (long)(F | 1) * RF_TH * 4 - 16;
     long cap = bytes / 8;
     cap = std::min<long>(cap, 2L * RF_NPRE * RF_LT) & ~1L;
     return (int)std::max<long>(cap, 0);
@@ -427,7 +435,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     for (int t = 0; t < n_trees; t++) {
         const int64_t b = tree_off[t], e = tree_off[t + 1];
         const int cnt = (int)(e - b);
-        if (cnt < 1 || cnt > 0xffffff) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "forest_load: tree %d has %d nodes (max 16777215)", t, cnt);
+        if (cnt < 1 || cnt > (int)RF_CHILD) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "forest_load: tree %d has %d nodes (max %u)", t, cnt, RF_CHILD);
         // breadth-first order; children of a node end up adjacent
         order.clear();
         newid.assign(cnt, -1);
@@ -483,7 +491,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
                 float f = (float)threshold[g];
                 if ((double)f > threshold[g]) f = nextafterf(f, -INFINITY);  // round toward -inf
                 nd.thr = f;
-                nd.bits = (unsigned)newid[left[g]] | ((unsigned)feature[g] << 24) | ((missing_go_left && missing_go_left[g]) ? RF_MISS : 0u);
+                nd.bits = (unsigned)newid[left[g]] | ((unsigned)feature[g] << 26) | ((missing_go_left && missing_go_left[g]) ? RF_MISS : 0u);  // byte 3 = 4 * feature
                 if (newid[right[g]] != newid[left[g]] + 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: internal layout error");
             }
         }
@@ -559,7 +567,7 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     if (fd.n_groups > 0) {
         // every group of trees fits the LDS: features 1024 * F * 4 B + cap nodes + the dummy leaf
         const int cap = rf_lds_cap(F);
-        const size_t lds = (size_t)F * RF_TH * 4 + (size_t)cap * sizeof(rf_node) + 16;
+        const size_t lds = (size_t)(F | 1) * RF_TH * 4 + (size_t)cap * sizeof(rf_node) + 16;
         auto launch = [&](auto kern) -> int {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             prof_scope ps(ctx, "forest");
