@@ -985,7 +985,18 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F + sizeof(double) * RSSEG_MAX_FEATURES + 64,
                                               sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
                                               sizeof(long long) * 2 * (size_t)M, (size_t)65536});
-    RSCHK(pin_reserve(ctx, pin_need));
+    // small host-to-device uploads (candidate rows, centres) go through a ring of pinned slots behind the read-back area:
+    // the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came from dies
+    // (a slot is reused four uploads later; every k-means++ round and every Lloyd iteration synchronises in between)
+    constexpr size_t UP_SLOT = 32 * 1024;
+    const size_t pin_main = (pin_need + 255) & ~(size_t)255;
+    RSCHK(pin_reserve(ctx, pin_main + 4 * UP_SLOT));
+    unsigned up_i = 0;
+    auto upload = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        char *slot = ctx->h_pin + pin_main + (size_t)(up_i++ & 3u) * UP_SLOT;
+        memcpy(slot, src, bytes);
+        return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+    };
     char *ws = ctx->d_ws;
     scaler_t<T> *d_sp = (scaler_t<T> *)(ws + o_sp);
     T *d_cen = (T *)(ws + o_cen);
@@ -1157,8 +1168,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         };
         for (int l = 0; l < cnt; l++) put(rows[l], l);
         if (pending) put(pending, KPP_MAXL);
-        HIPCHK(ctx, hipMemcpyAsync(d_cand, flat, sizeof(flat), hipMemcpyHostToDevice, st));  // one copy: rows + norms
-        HIPCHK(ctx, hipStreamSynchronize(st));  // flat lives on this stack frame
+        static_assert(sizeof(flat) <= UP_SLOT, "upload slot too small");
+        HIPCHK(ctx, upload(d_cand, flat, sizeof(flat)));  // one copy: rows + norms
         return RSSEG_OK;
     };
     // per-rank totals of the local chunk partials (row `row` of d_part), and the local prefix table
@@ -1359,8 +1370,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             }
             csq[j] = a;
         }
-        HIPCHK(ctx, hipMemcpyAsync(d_cen, cenT, sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX), hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        static_assert(sizeof(cenT) <= UP_SLOT, "upload slot too small");
+        HIPCHK(ctx, upload(d_cen, cenT, sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX)));
         if (n > 0) {
             {
                 prof_scope ps(ctx, "lloyd");
