@@ -633,6 +633,23 @@ def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
     assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("F", [1, 2, 8, 32])
+def test_forest_feature_counts_vs_sklearn(ctx, oracle, F):
+    """Feature counts 1, even, and the maximum (32): a pixel's features are one LDS row of F | 1 floats and a node's
+    byte 3 is 4 x feature; NaN rows included; a pixel count that leaves the last workgroup ragged."""
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(100 + F)
+    Xtr = rng.random((4000, F)).astype(np.float32)
+    ytr = ((Xtr.sum(1) * 3).astype(np.int64) + (rng.random(4000) < 0.1) * rng.integers(0, 4, 4000)) % 4
+    model = RandomForestClassifier(n_estimators=9, max_depth=8, random_state=F, n_jobs=4).fit(Xtr, ytr)
+    X = rng.random((3001, F)).astype(np.float32)
+    X[::29, F - 1] = np.nan
+    X[3::31, 0] = np.nan
+    ctx.forest_load(oracle.flatten_forest(model))
+    got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(F)]))
+    assert np.array_equal(got, model.predict(X))
+
+
 def test_forest_large_trees_many_classes_and_infinities_vs_sklearn(ctx, oracle):
     """(a) Unpruned trees with more nodes than the LDS holds (the general kernel: upper levels in LDS, deeper nodes by
     global loads), with NaN rows; (b) 11 and 20 classes (sklearn has no class limit; the wider vote tables);
