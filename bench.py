@@ -108,6 +108,17 @@ def pmc_traffic_bytes(family, px):
     return None
 
 
+def pattern_rate_gbs(family):
+    """Measured rate (GB/s) of the family's bare access pattern on MI355X — 15 float32 planes read with 16-byte loads, plus
+    one read-modify-write plane for the k-means kernels (profiles/r02_streams.json, best of the recorded runs) — or None."""
+    try:
+        runs = json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]
+        key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("with_rw_plane", "15"), "moment": ("read_only", "15")}[family]
+        return round(max(r[key][ns] for r in runs if key in r) * 1000.0, 1)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def glcm_issue_cycles(glcm_step=1):
     """(weighted VALU issue cycles per wave, windows per wave, static VALU instructions per wave, kernel) of the texture
     kernel that runs at this step, from the committed microbenchmark summary; cycles None when it is absent."""
@@ -309,6 +320,10 @@ def main():
                    "hbm_GBs": round(px * bpp / per_launch_s / 1e9, 1), "hbm_frac": round(px * bpp / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)}
             if bound == "hbm":
                 ent["frac"] = ent["hbm_frac"]
+                rate = pattern_rate_gbs(fam)
+                if rate:   # what a kernel with nothing but this access pattern reaches (profiles/ubench/streams.hip)
+                    ent["pattern_rate_GBs"] = rate
+                    ent["frac_of_pattern_rate"] = round(ent["hbm_GBs"] / rate, 4)
             elif bound == "valu" and cfg != "c3":
                 ent["frac"] = None      # window 21 / step 21 runs the workgroup-per-window kernel: no instruction model for it
             elif bound == "valu":
