@@ -275,7 +275,12 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
 # one raster, row stripes over the ranks (BASELINE config 4)
 # ------------------------------------------------------------------------------------------------
 def stripe_rows(H: int, world: int, rank: int) -> Tuple[int, int]:
-    """Rows [r0, r1) owned by `rank`: contiguous stripes in rank order."""
+    """Rows [r0, r1) owned by `rank`: contiguous stripes in rank order.  Every rank owns at least one row (the same check
+    fails on every rank, so nobody is left waiting in a collective)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"stripe_rows: rank {rank} outside a world of {world}")
+    if H < world:
+        raise ValueError(f"stripe_rows: {H} rows cannot be split over {world} ranks (a rank would own no row)")
     return (H * rank) // world, (H * (rank + 1)) // world
 
 

@@ -226,3 +226,15 @@ def test_feature_dict_plumbing_matches_reference_key_rule(golden_dir, tmp_path):
     with pytest.raises(ValueError):
         open(str(tmp_path / "x.txt"), "w").write("x")
         load_features(str(tmp_path / "x.txt"))
+
+
+def test_stripe_rows_cover_the_raster_and_refuse_empty_stripes():
+    from rsseg import pipeline as P
+    for H, world in ((16384, 8), (203, 5), (9, 8), (8, 8)):
+        rows = [P.stripe_rows(H, world, r) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == H
+        assert all(a[1] == b[0] for a, b in zip(rows, rows[1:])) and all(r1 > r0 for r0, r1 in rows)
+    with pytest.raises(ValueError):
+        P.stripe_rows(7, 8, 0)
+    with pytest.raises(ValueError):
+        P.stripe_rows(100, 4, 4)
