@@ -994,3 +994,30 @@ def test_normalise_division_is_the_ieee_quotient(ctx):
         got = ctx.normalize(dev(ctx, x), float(lo), float(hi)).cpu().numpy()
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), (lo, hi, x[~same][:4], got[~same][:4], want[~same][:4])
+
+
+def test_full_size_depth16_forest_vs_sklearn(ctx):
+    """BASELINE config 5 at its real size with its real forest: RandomForestClassifier(100 trees, max_depth 16) fitted on
+    the 19-feature stack (bench.fit_c5_forest, the same object the bench walks), the 16384 x 16384 stack classified on
+    the GPU, 30 000 pixels drawn over the whole raster (the last rows included) against model.predict on the same rows."""
+    import torch
+    import bench
+    from rsseg import pipeline as P
+    H = W = 16384
+    fm = bench.fit_c5_forest(torch, None, ctx.device, P, 0, 1, W)
+    depths = [e.tree_.max_depth for e in fm["model"].estimators_]
+    assert len(depths) == 100 and max(depths) == 16
+    ctx.forest_load(fm["flat"])
+    bands = bench.synth_rows(torch, ctx.device, W, 0, H)
+    planes, _ = P.feature_stack19(ctx, bands, H, W)
+    fp = P.stack19_forest_planes(ctx, planes)
+    got = ctx.forest_predict(fp)
+    rng = np.random.default_rng(16)
+    idx = np.concatenate([rng.choice(H * W, 29000, replace=False), np.arange(H * W - 1000, H * W)])
+    ti = torch.from_numpy(idx).to(ctx.device)
+    X = np.stack([p[ti].cpu().numpy() for p in fp], 1)
+    want = fm["model"].predict(X)
+    assert np.array_equal(got[ti].cpu().numpy(), want)
+    assert len(np.unique(want)) >= 6   # a real multi-class map, not one label
+    del planes, fp, bands, got
+    torch.cuda.empty_cache()
