@@ -72,6 +72,12 @@ struct rf_group {   // k11_forest_lds: trees [first, first + count) whose nodes 
 
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef __attribute__((address_space(3))) const rf_node lds_cnode;
+// an LDS address is 32 bits wide on the device; the host pass of the same source sees 64-bit pointers and would warn
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_LDS_PTR(T, a) ((T *)(a))
+#else
+#define RF_LDS_PTR(T, a) ((T *)(uintptr_t)(a))
+#endif
 
 // The vote of a leaf: its row of the table, added in tree order (x + 0.0 == x, so a one-hot row adds a single 1.0).
 template <int NC>
@@ -135,13 +141,13 @@ __device__ __forceinline__ void rf_round_lds(rf_node (&nd)[RF_NCH], unsigned fea
     float x[RF_NCH];
 #pragma unroll
     for (int q = 0; q < RF_NCH; q++)   // chain q: pixel q / RF_C of the thread, tree q % RF_C of the group
-        x[q] = *(lds_cfloat *)(feat_tid + (q / RF_C) * px_stride + (nd[q].bits >> 24));
+        x[q] = *RF_LDS_PTR(lds_cfloat, feat_tid + (q / RF_C) * px_stride + (nd[q].bits >> 24));
 #pragma unroll
     for (int q = 0; q < RF_NCH; q++) {
         bool go_right = x[q] > nd[q].thr;
         if (NANS) go_right = go_right || (x[q] != x[q] && !(nd[q].bits & RF_MISS));
         const unsigned next = (nd[q].bits & RF_CHILD) + (go_right ? 1u : 0u);
-        lds_cnode *p = (lds_cnode *)(base[q % RF_C] + next * 8u);
+        lds_cnode *p = RF_LDS_PTR(lds_cnode, base[q % RF_C] + next * 8u);
         nd[q].thr = p->thr;
         nd[q].bits = p->bits;
     }
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
         for (int c = 0; c < RF_C; c++) {
             const rf_tree tr = trees[c < gr.count ? gr.first + c : gr.first];
             base[c] = c < gr.count ? top_addr + (unsigned)(tr.node_off - gr.node_base) * 8u : top_addr + (unsigned)cap2 * 16u;
-            lds_cnode *p = (lds_cnode *)base[c];
+            lds_cnode *p = RF_LDS_PTR(lds_cnode, base[c]);
 #pragma unroll
             for (int px = 0; px < RF_PX; px++) {   // lanes without a pixel walk their zero features (no special case in the loop)
                 nd[px * RF_C + c].thr = p->thr;
