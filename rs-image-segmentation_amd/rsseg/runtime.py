@@ -177,6 +177,15 @@ class Context:
         a = np.ascontiguousarray(a, dtype=dtype)
         return torch.from_numpy(a).to(self.device)
 
+    def upload_f32(self, a: np.ndarray):
+        """A band as a flat float32 device plane — the reference's `.astype(np.float32)` (extract.py:34).  An 8-bit raster
+        crosses PCIe as 1 byte per pixel and is widened on the device (exact: every uint8 is a float32)."""
+        torch = _torch()
+        a = np.ascontiguousarray(a).reshape(-1)
+        if a.dtype == np.uint8:
+            return torch.from_numpy(a).to(self.device).to(torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
     def empty(self, n, dtype):
         torch = _torch()
         t = torch.empty(int(n), dtype=dtype, device=self.device)

@@ -28,7 +28,7 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     ignored exactly as in the reference (NIR = bands[3] is hard-wired, scripts/2:84)."""
     ctx = ctx or default_context()
     h, w = np.asarray(bands_data[0]).shape
-    dev = [ctx.to_device(np.ascontiguousarray(b, dtype=np.float32).reshape(-1)) for b in bands_data if b is not None]
+    dev = [ctx.upload_f32(np.asarray(b)) for b in bands_data if b is not None]
     planes, ex = P.feature_stack19(ctx, dev, h, w, preprocessing=bool(preprocessing))   # False: bands taken as given (scripts/2:43-50)
 
     def host(t):

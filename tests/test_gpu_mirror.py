@@ -57,6 +57,21 @@ def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
     assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(nir)) and fr["laplacian"].dtype == np.float32
 
 
+def test_stage_takes_uint8_bands_like_float32_bands(ctx, crop):
+    """8-bit rasters cross PCIe as one byte per pixel and are widened on the device (Context.upload_f32): the stage's
+    outputs equal those of the same bands handed over as float32, bit for bit."""
+    import torch
+    from rsseg import stages
+    b32 = [np.asarray(b, np.float32) for b in crop["bands"]]
+    assert all(np.array_equal(b, np.round(b)) and b.min() >= 0 and b.max() <= 255 for b in b32)
+    b8 = [b.astype(np.uint8) for b in b32]
+    assert torch.equal(ctx.upload_f32(b8[0]), ctx.to_device(b32[0].reshape(-1)))
+    fd32, h32 = stages.run_feature_extraction_stage(b32)
+    fd8, h8 = stages.run_feature_extraction_stage(b8)
+    assert np.array_equal(h32["all"], h8["all"], equal_nan=True)
+    assert np.array_equal(fd32["ndvi"], fd8["ndvi"]) and np.array_equal(fd32["lbp_feature"], fd8["lbp_feature"])
+
+
 def test_stage_function_layout_and_files(ctx, crop, tmp_path, oracle):
     from rsseg import stages
     fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
