@@ -163,6 +163,55 @@ def cpu_baseline(tile_bands, H, W, crop, cfg, k, glcm_step, model=None):
                        + f"; extrapolated linearly in pixels to the full raster; {tot_all:.1f} s all cores, {tot_one:.1f} s one thread")}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` run bare (no torchrun): start N FRESH child processes of this script, one per GPU, with
+    the rendezvous environment torch.distributed.run would give them, wait for all of them, relay rank 0's single JSON
+    line and return a non-zero code if any rank failed.  Nothing in this (parent) process has touched a GPU: torch is
+    not even imported yet, and the children are new processes, not an exec of an initialised one."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RSSEG_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines[-1:]:
+            print(ln, file=sys.stderr)
+    if any(codes) or not json_lines:
+        print(f"bench.py: ranks exited with {codes}" + ("" if json_lines else "; rank 0 printed no JSON line"), file=sys.stderr)
+        return max([abs(c) for c in codes if c] + [1])
+    print(json_lines[-1], flush=True)
+    return 0
+
+
+def launch_selftest():
+    """--launch-selftest: what a rank does to prove the launch without a GPU — rendezvous over gloo on the CPU, one
+    all-reduce, rank 0 prints the line (used by tests/test_host.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    total = 1.0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        total = float(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "sum_of_rank_ids_plus_1": total}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +227,21 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="c3, N = 1: GLCM chain on a second HIP stream (profiles/r01_overlap_note.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--launch-selftest", action="store_true", help="no GPU: every rank joins a gloo rendezvous on the CPU and rank 0 prints one line")
     args = ap.parse_args()
+
+    # ---- N ranks: either torch.distributed.run started us (RANK / WORLD_SIZE set, WORLD_SIZE must equal --gpus), or
+    # this process starts them itself.  Decided BEFORE torch is imported or a GPU is touched.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}, "
+                         "or run bench.py bare and let it start the ranks")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launch_selftest:
+        raise SystemExit(launch_selftest())
 
     import torch
     import torch.distributed as dist

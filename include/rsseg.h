@@ -46,7 +46,7 @@ extern "C" {
 #define RSSEG_BORDER_REFLECT 0     /* cv2.BORDER_REFLECT      fedcba|abcdefgh|hgfedcb */
 #define RSSEG_BORDER_REFLECT101 1  /* cv2.BORDER_REFLECT_101  gfedcb|abcdefgh|gfedcba */
 
-#define RSSEG_MAX_FEATURES 32
+#define RSSEG_MAX_FEATURES 64
 #define RSSEG_MAX_CLUSTERS 64
 #define RSSEG_MAX_RANKS 16
 
@@ -269,6 +269,10 @@ int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes, int F, in
 /* threshold_segmentation (modules/features/extract.py:344-404, otsu=False): NaN counts as 0, then d_out = 1 where
  * lo < x < hi, else 0 (pass -INFINITY / INFINITY for `x > t` / `x < t`). */
 int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, uint8_t *d_out);
+/* The band conditions of extract_bareland_by_rule (extract.py:486-497: np.logical_and(x > lo, x < hi) on the raw plane):
+ * nan_as_zero = 0 leaves a NaN pixel outside every interval (both comparisons are false); nan_as_zero = 1 is
+ * rsseg_threshold_band_f32. */
+int rsseg_band_interval_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, int nan_as_zero, uint8_t *d_out);
 /* Mask algebra of extract_builtup_by_threshold / extract_bareland_by_rule (extract.py:447-505) on 0 / 1 planes:
  * op 0: a & b, 1: a | b, 2: a & !b, 3: !a (d_b may be NULL).  d_out may alias an input. */
 int rsseg_mask_op_u8(rsseg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int64_t n, int op, uint8_t *d_out);

@@ -50,6 +50,56 @@ def import_reference():
     return ref_idx, ref_ext, ref_sup
 
 
+def stage2_fixture(ref_idx, ref_ext, O, bands, report):
+    """tests/golden/crop96_stage2.npz: the DEFAULT call of the reference's unsupervised_kmeans_classification
+    (feature_keys_to_use=None, extract.py:516-522) on a dict shaped like the pickle scripts/2_feature_extraction.py:222-232
+    writes, pushed through the reference's normalize_features_structure: 55 two-dimensional planes (7 indices, 7 PCA
+    components, 5 GLCM, LBP, 15 multi-scale, 15 morphological, 5 filter members; float32 and float64 mixed -> a float64
+    matrix).  Indices and PCA planes come from the reference functions, the cv2 / skimage members from the oracle."""
+    from threadpoolctl import threadpool_limits
+    import contextlib
+    import io
+    y0, x0, S = 250, 180, 96
+    crop = [np.ascontiguousarray(b[y0:y0 + S, x0:x0 + S]) for b in bands]
+    with threadpool_limits(limits=1):
+        norm = [ref_idx.robust_normalize(b) for b in crop]
+        pca7, _, _ = ref_idx.perform_pca(norm, use_robust_scaling=True)
+        fd = O.full_features_dict(crop, pca_result=pca7)
+        blue, green, red, nir, swir1 = norm[:5]
+        ref_members = {"ndvi": ref_idx.calculate_ndvi(nir, red), "evi": ref_idx.calculate_evi(nir, red, blue),
+                       "msavi": ref_idx.calculate_msavi(nir, red), "ndwi": ref_idx.calculate_ndwi(green, nir),
+                       "mndwi": ref_idx.calculate_mndwi(green, swir1), "ndbi": ref_idx.calculate_ndbi(swir1, nir),
+                       "bsi": ref_idx.calculate_bsi(blue, red, nir, swir1)}
+        for k, v in ref_members.items():
+            assert np.array_equal(fd[k], v, equal_nan=True), k
+        _, hier = O.run_feature_extraction_stage(crop, glcm_window=21, glcm_step=21)
+        pickle_like = {"hierarchical_features": hier, "all_extracted_features_dict": fd, "dimensions": (S, S),
+                       "geo_transform": None, "crs": None}
+
+        class _Affine:  # stands in for affine.Affine inside the reference module (isinstance check only)
+            pass
+        ref_ext.Affine = _Affine
+        with contextlib.redirect_stdout(io.StringIO()):
+            nf = ref_ext.normalize_features_structure(pickle_like)
+        keys2d = [k for k, v in nf.items() if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == (S, S)]
+        flat = O.flatten_features_dict(fd)
+        assert keys2d == list(flat), (keys2d, list(flat))
+        out = {"keys": np.array(keys2d), "height": S, "width": S}
+        for i, k in enumerate(keys2d):
+            out[f"plane_{i:02d}"] = nf[k]
+        labels = {}
+        for kk in (5, 8):
+            with contextlib.redirect_stdout(io.StringIO()):
+                labels[kk] = ref_ext.unsupervised_kmeans_classification(nf, kk, None).astype(np.int32)
+            out[f"kmeans_auto_k{kk}"] = labels[kk]
+    np.savez_compressed(os.path.join(OUT, "crop96_stage2.npz"), **out)
+    for kk in (5, 8):
+        lab, info = O.kmeans_fit_planes([nf[k] for k in keys2d], kk)
+        report[f"kmeans_stage2_55planes_k{kk}"] = dict(mismatch=int(np.sum(lab != labels[kk].reshape(-1))), n=int(lab.size),
+                                                       n_iter=info["n_iter"], n_features=len(keys2d))
+    return report
+
+
 def main():
     warnings.filterwarnings("ignore")
     from threadpoolctl import threadpool_limits
@@ -62,6 +112,15 @@ def main():
 
     os.makedirs(OUT, exist_ok=True)
     report = {}
+    if "--only-stage2" in sys.argv:   # add the 55-plane fixture without rewriting the others
+        dn = read_tiff(os.path.join(REF, "data/raw/AA.tif"))
+        with open(os.path.join(OUT, "PIN_REPORT.json")) as f:
+            report = json.load(f)
+        stage2_fixture(ref_idx, ref_ext, O, O.stage1_preprocess(dn), report)
+        with open(os.path.join(OUT, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        print(json.dumps({k: v for k, v in report.items() if "stage2" in k}, indent=1))
+        return
 
     # ---------------- inputs: the bundled scene (data file of the reference) ----------------
     dn = read_tiff(os.path.join(REF, "data/raw/AA.tif"))
@@ -216,6 +275,8 @@ def main():
     with open(os.path.join(OUT, "nfs_golden.json"), "w") as f:
         json.dump(nfs, f, indent=1)
     report["nfs_keys"] = nfs["keys"]
+
+    stage2_fixture(ref_idx, ref_ext, O, bands, report)
 
     import sklearn
     report["versions"] = dict(numpy=np.__version__, sklearn=sklearn.__version__)

@@ -17,7 +17,7 @@
 typedef __int128 i128;
 typedef unsigned __int128 u128;
 
-#define MAXF 32
+#define MAXF 64
 #define MAXK 64
 #define FX_ONE 1099511627776.0          /* 2^40 */
 #define FX_INV (1.0 / 1099511627776.0)  /* 2^-40 */

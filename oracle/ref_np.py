@@ -442,6 +442,77 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     return fd, hier
 
 
+def full_features_dict(bands_data: Sequence[np.ndarray], preprocessing=True, glcm_window=21, glcm_step=21, glcm_levels=32,
+                       pca_result=None) -> Dict[str, object]:
+    """EVERY member of features_dict as scripts/2_feature_extraction.py:62-106 fills it, in the reference's insertion
+    order (the order decides the column order of unsupervised_kmeans_classification's default key selection,
+    extract.py:516-522): 7 indices, pca_result, variance_ratio, glcm_features (indices.py:310-316), lbp_feature,
+    multi_scale_features (per scale 1/3/5/7: mean, variance, std_dev, entropy for scales <= 5, indices.py:535-560),
+    morphological_features (per size 3/5/7: erosion .. gradient, :421-440), filter_features (:463-480).
+    pca_result (optional): the component planes to use instead of the restatement's (fixtures take the reference's)."""
+    if preprocessing:
+        bands_data = [robust_normalize(b) for b in bands_data]
+    blue, green, red, nir, swir1 = bands_data[:5]
+    fd: Dict[str, object] = {}
+    fd["ndvi"] = calculate_ndvi(nir, red)
+    fd["evi"] = calculate_evi(nir, red, blue)
+    fd["msavi"] = calculate_msavi(nir, red)
+    fd["ndwi"] = calculate_ndwi(green, nir)
+    fd["mndwi"] = calculate_mndwi(green, swir1)
+    fd["ndbi"] = calculate_ndbi(swir1, nir)
+    fd["bsi"] = calculate_bsi(blue, red, nir, swir1)
+    if pca_result is None:
+        pca_result, ratio, _ = perform_pca([b for b in bands_data if b is not None])
+    else:
+        ratio = np.zeros(len(pca_result), np.float32)
+    fd["pca_result"] = list(pca_result)
+    fd["variance_ratio"] = ratio
+    fd["glcm_features"], _ = calculate_glcm_features(nir, glcm_levels, glcm_window, glcm_step)
+    b = robust_normalize(nir)            # every texture function re-normalises the band it receives
+    u8 = to_u8(b)
+    lbp = lbp_uniform(u8, 24, 3)
+    fd["lbp_feature"] = lbp / lbp.max()
+    ms: Dict[str, np.ndarray] = {}
+    for scale in (1, 3, 5, 7):
+        mean = b.copy() if scale == 1 else box_mean(b, scale, "reflect101")       # cv2.blur with a 1x1 kernel is the identity
+        mean_sq = b * b if scale == 1 else box_mean(b * b, scale, "reflect101")
+        var = mean_sq - mean * mean
+        var[var < 0] = 0
+        ms[f"mean_scale_{scale}"] = mean
+        ms[f"variance_scale_{scale}"] = var
+        ms[f"std_dev_scale_{scale}"] = np.sqrt(var)
+        if scale <= 5:
+            e = rank_entropy(u8, scale)
+            ms[f"entropy_scale_{scale}"] = e / np.max(e)
+    fd["multi_scale_features"] = ms
+    fd["morphological_features"] = calculate_morphological_features(nir)
+    ff = filter_responses_extra(nir)
+    ff["laplacian"] = laplacian_feature(nir)
+    ff["sobel_mag"] = sobel_mag_feature(nir)
+    fd["filter_features"] = ff
+    return fd
+
+
+def flatten_features_dict(fd: Dict[str, object], prefix: str = "all_extracted_features_dict") -> Dict[str, np.ndarray]:
+    """The 2-D members of a stage-2 features_dict under the keys normalize_features_structure gives them
+    (extract.py:139-174: '<outer>_<inner>' lower-case, list members by index), in the same order."""
+    out: Dict[str, np.ndarray] = {}
+
+    def walk(v, key):
+        if isinstance(v, np.ndarray) and v.ndim >= 2:
+            out.setdefault(key.lower(), v)
+        elif isinstance(v, dict):
+            for k2, v2 in v.items():
+                walk(v2, f"{key}_{k2}")
+        elif isinstance(v, list):
+            for i, v2 in enumerate(v):
+                walk(v2, f"{key}_{i}")
+
+    for k, v in fd.items():
+        walk(v, f"{prefix}_{k}" if prefix else k)
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # LBP, rank entropy, fixed-point Gaussian (indices.py:320-344, 551-560, 463-470) — scikit-image / OpenCV semantics restated
 # from their published algorithms (libraries absent, unpinned in the reference: parity unpinned)

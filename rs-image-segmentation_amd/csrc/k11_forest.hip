@@ -8,17 +8,20 @@
 //
 // Forest layout (built once by rsseg_forest_load): every tree is renumbered in BREADTH-FIRST order, so the two children
 // of a node are adjacent (left = c, right = c + 1) and a node is 8 bytes:
-//   internal  { float thr ; uint32 : bits 0-23 left child, 24-29 feature, 30 missing->left }
-//   leaf      { NaN whose payload (bits 0-21) is the leaf's row in the vote table ; uint32 : bits 0-23 the leaf's OWN index,
-//               bit 30, bit 31 }
-// Vote table: rows of NC = 4 / 8 / 16 / 32 float64 (n_classes padded with zeros); rows 0 .. n_classes-1 are the one-hot
+//   internal  { float thr ; uint32 : bits 0-21 left child, bit 22 missing->left, bit 23 = 0, byte 3 = 4 * feature }
+//   leaf      { NaN whose payload (bits 0-21) is the leaf's row in the vote table ; uint32 : bits 0-21 the leaf's OWN index,
+//               bit 22 and bit 23 (leaf) set, byte 3 = 0 }
+// Vote table: rows of NC = 4 / 8 / 16 / 32 / 64 float64 (n_classes padded with zeros); rows 0 .. n_classes-1 are the one-hot
 // rows shared by every pure leaf, the mixed leaves follow.  Every leaf votes the same way — acc[c] += row[c], 16-byte
 // loads, no branch; pure leaves of a wave hit the same few cache lines.
 // `X[i,f] <= threshold` compares a float32 feature with a float64 threshold; that is equivalent to comparing with the
 // threshold rounded DOWN to float32, which is what thr holds.  A walk step is next = left + (x > thr): on a leaf
 // x > NaN is false for every x, so the step returns the leaf itself — leaves are fixed points and the inner loop needs
 // no leaf test per chain, no select and no branch.
-// The pixel's features are staged once in LDS ([F][1024] floats, bank = lane, conflict-free for any per-lane feature).
+// The pixel's features are staged once in LDS (one row of F | 1 floats per pixel; 1024 pixels per workgroup up to 32
+// features and 32 classes, 512 beyond — up to RSSEG_MAX_FEATURES = 64 features, 64 classes — so that the rows still
+// leave room for tree nodes: the reference's non-hierarchical forest branch stacks every 2-D plane of the feature
+// dictionary, scripts/3_classification.py:425-437).
 //
 // Two kernels:
 //   k11_forest_lds   trees are taken in groups of <= 4 consecutive trees whose nodes (contiguous in the node array) fit
@@ -49,9 +52,9 @@ struct __align__(8) rf_node {
 #define RF_NAN_BITS 0x7fc00000u   // leaf thr: quiet NaN | payload
 #define RF_PAY_MASK 0x003fffffu   // payload: row of the vote table
 
-#define RF_NCMAX 32
+#define RF_NCMAX 64
+static_assert(RSSEG_MAX_FEATURES <= 64, "byte 3 of a node holds 4 * feature");
 #define RF_C 4        // trees walked at a time (independent chains of dependent LDS reads)
-#define RF_TH 1024    // pixels per workgroup
 
 struct rf_planes {
     const float *p[RSSEG_MAX_FEATURES];
@@ -115,13 +118,14 @@ __device__ __forceinline__ void rf_finish(const double (&acc)[NC], int n_trees, 
     out[i] = classes[best];
 }
 
+template <int TH>
 __device__ __forceinline__ int rf_stage_features(const rf_planes &pl, int F, int64_t n, int64_t i, float *feat)
 {
     int my_nan = 0;
     for (int f = 0; f < F; f++) {
         const float v = i < n ? pl.p[f][i] : 0.f;
         my_nan |= v != v;
-        feat[f * RF_TH + threadIdx.x] = v;
+        feat[f * TH + threadIdx.x] = v;
     }
     return my_nan;
 }
@@ -130,8 +134,7 @@ __device__ __forceinline__ int rf_stage_features(const rf_planes &pl, int F, int
 // A thread owns RF_PX pixels of its workgroup's 1024 and walks RF_C trees for each: RF_PX * RF_C independent chains.
 // One round advances every chain by one node: all feature reads back to back, all node reads back to back, no control
 // flow (leaves are fixed points).  Lanes leave the loop when all their chains sit on leaves.
-#define RF_PX 1                      // pixels per thread (k11_forest_lds): 512 threads per workgroup
-#define RF_LT (RF_TH / RF_PX)
+#define RF_PX 1                      // pixels per thread (k11_forest_lds): TH threads per workgroup
 #define RF_NCH (RF_PX * RF_C)
 
 template <bool NANS>
@@ -171,13 +174,14 @@ __device__ __forceinline__ void rf_walk_lds(rf_node (&nd)[RF_NCH], unsigned feat
 
 #define RF_NPRE (6 * RF_PX)   // 16-byte pieces (2 nodes) a thread prefetches per group: cap <= 12 * 1024 nodes
 
-template <int NC>
-__global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
+template <int NC, int RF_TH>
+__global__ __launch_bounds__(RF_TH) void k11_forest_lds(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
                                                         const rf_tree *__restrict__ trees, const rf_group *__restrict__ groups, int n_groups,
                                                         int cap2 /* node area in 16-byte pieces */, int two_rounds, int n_trees,
                                                         const double *__restrict__ leafval,
                                                         int n_classes, const long long *__restrict__ classes, long long *__restrict__ out)
 {
+    constexpr int RF_LT = RF_TH / RF_PX;
     extern __shared__ __align__(16) char smem[];
     const int FP = F | 1;                                                      // odd row length: the fills below hit 64 distinct banks
     float *feat = reinterpret_cast<float *>(smem);                             // [RF_TH pixels][FP]
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(RF_LT) void k11_forest_lds(rf_planes pl, int F, int
 // Every load of a round is issued unconditionally (a chain on its leaf reads node 0 of its block and keeps its leaf by a
 // select): a load inside a per-chain `if` makes the compiler wait for each LDS read before it issues the next one,
 // which serialises the chains.  Only a step to a node beyond the LDS block takes a predicated global load.
-template <bool NANS>
+template <bool NANS, int RF_TH>
 __device__ __forceinline__ void rf_walk_gen(rf_node (&nd)[RF_C], lds_cfloat *feat, lds_cnode *top, int ntop, const int (&lim)[RF_C],
                                             const rf_node *__restrict__ nodes, const int (&noff)[RF_C])
 {
@@ -318,7 +322,7 @@ __device__ __forceinline__ void rf_walk_gen(rf_node (&nd)[RF_C], lds_cfloat *fea
     }
 }
 
-template <int NC>
+template <int NC, int RF_TH>
 __global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int64_t n, const rf_node *__restrict__ nodes,
                                                         const rf_tree *__restrict__ trees, int n_trees, int ntop,
                                                         const double *__restrict__ leafval, int n_classes,
@@ -328,8 +332,8 @@ __global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int
     float *feat = reinterpret_cast<float *>(smem);                                   // [F][RF_TH]
     rf_node *top = reinterpret_cast<rf_node *>(feat + (size_t)F * RF_TH);            // [RF_C][ntop]
     const int64_t i = (int64_t)blockIdx.x * RF_TH + threadIdx.x;
-    const int my_nan = rf_stage_features(pl, F, n, i, feat);
-    constexpr int NPRE = 12;  // RF_C * ntop <= 12 * 1024 nodes per group (host keeps ntop <= 3072)
+    const int my_nan = rf_stage_features<RF_TH>(pl, F, n, i, feat);
+    constexpr int NPRE = 12;  // RF_C * ntop <= 12 * RF_TH nodes per group (the host keeps ntop <= 3 * RF_TH)
     for (int c = 0; c < RF_C && c < n_trees; c++) {
         const rf_tree t0 = trees[c];
         const int cnt = t0.n_nodes < ntop ? t0.n_nodes : ntop;
@@ -382,8 +386,8 @@ __global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int
                 nd[c].bits = ltop[c * ntop].bits;
                 if (t + c >= n_trees || i >= n) nd[c].bits = RF_LEAF;  // no tree / no pixel: nothing to walk
             }
-            if (any_nan) rf_walk_gen<true>(nd, lfeat, ltop, ntop, lim, nodes, noff);
-            else rf_walk_gen<false>(nd, lfeat, ltop, ntop, lim, nodes, noff);
+            if (any_nan) rf_walk_gen<true, RF_TH>(nd, lfeat, ltop, ntop, lim, nodes, noff);
+            else rf_walk_gen<false, RF_TH>(nd, lfeat, ltop, ntop, lim, nodes, noff);
             if (i < n) {
 #pragma unroll
                 for (int c = 0; c < RF_C; c++)
@@ -410,12 +414,14 @@ __global__ __launch_bounds__(RF_TH) void k11_forest_gen(rf_planes pl, int F, int
     if (i < n) rf_finish<NC>(acc, n_trees, n_classes, classes, out, i);
 }
 
-// nodes of a tree group that fit the LDS beside the features of 1024 pixels (one 16-byte piece is kept for the dummy leaf)
-static int rf_lds_cap(int F)
+// pixels per workgroup: 1024 while the feature rows and the vote accumulators allow it
+static int rf_threads(int F, int n_classes) { return (F <= 32 && n_classes <= 32) ? 1024 : 512; }
+// nodes of a tree group that fit the LDS beside the features of TH pixels (one 16-byte piece is kept for the dummy leaf)
+static int rf_lds_cap(int F, int TH)
 {
-    const long bytes = 160L * 1024 - 256 - (long)(F | 1) * RF_TH * 4 - 16;
+    const long bytes = 160L * 1024 - 256 - (long)(F | 1) * TH * 4 - 16;
     long cap = bytes / 8;
-    cap = std::min<long>(cap, 2L * RF_NPRE * RF_LT) & ~1L;
+    cap = std::min<long>(cap, 2L * RF_NPRE * (TH / RF_PX)) & ~1L;
     return (int)std::max<long>(cap, 0);
 }
 
@@ -432,7 +438,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     const int64_t nn = tree_off[n_trees];
     if (nn < n_trees || nn > 0x7ffffff0) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: bad node count %lld", (long long)nn);
     std::vector<rf_node> nodes((size_t)nn);
-    const int NCP = n_classes <= 4 ? 4 : (n_classes <= 8 ? 8 : (n_classes <= 16 ? 16 : 32));  // row length of the vote table
+    const int NCP = n_classes <= 4 ? 4 : (n_classes <= 8 ? 8 : (n_classes <= 16 ? 16 : (n_classes <= 32 ? 32 : 64)));  // row length of the vote table
     std::vector<double> leaf((size_t)n_classes * NCP, 0.0);
     for (int c = 0; c < n_classes; c++) leaf[(size_t)c * NCP + c] = 1.0;
     std::vector<rf_tree> trees(n_trees);
@@ -503,7 +509,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
         }
     }
     // ---- plan of k11_forest_lds: groups of <= RF_C consecutive trees whose nodes fit the LDS beside the features ----
-    const int cap = rf_lds_cap(n_features);
+    const int cap = rf_lds_cap(n_features, rf_threads(n_features, n_classes));
     std::vector<rf_group> groups;
     bool fits = true;
     for (int t = 0; t < n_trees && fits;) {
@@ -568,40 +574,57 @@ extern "C" int rsseg_forest_predict(rsseg_ctx *ctx, const float *const *d_planes
     if (n == 0) return RSSEG_OK;
     const long long *d_classes = (const long long *)fd.d_treeoff;
     const rf_tree *d_trees = (const rf_tree *)((const char *)fd.d_treeoff + fd.n_classes * sizeof(long long));
-    const unsigned grid = (unsigned)ceil_div64(n, RF_TH);
+    const int TH = rf_threads(F, fd.n_classes);
+    const unsigned grid = (unsigned)ceil_div64(n, TH);
     int rc;
     if (fd.n_groups > 0) {
-        // every group of trees fits the LDS: features 1024 * F * 4 B + cap nodes + the dummy leaf
-        const int cap = rf_lds_cap(F);
-        const size_t lds = (size_t)(F | 1) * RF_TH * 4 + (size_t)cap * sizeof(rf_node) + 16;
+        // every group of trees fits the LDS: features TH * (F | 1) * 4 B + cap nodes + the dummy leaf
+        const int cap = rf_lds_cap(F, TH);
+        const size_t lds = (size_t)(F | 1) * TH * 4 + (size_t)cap * sizeof(rf_node) + 16;
         auto launch = [&](auto kern) -> int {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             prof_scope ps(ctx, "forest");
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_LT), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(TH / RF_PX), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees,
                                (const rf_group *)fd.d_groups, fd.n_groups, cap / 2, fd.max_depth >= 10 ? 1 : 0, fd.n_trees, (const double *)fd.d_leafval, fd.n_classes, d_classes,
                                (long long *)d_out);
             return RSSEG_OK;
         };
-        if (fd.n_classes <= 4) rc = launch(k11_forest_lds<4>);
-        else if (fd.n_classes <= 8) rc = launch(k11_forest_lds<8>);
-        else if (fd.n_classes <= 16) rc = launch(k11_forest_lds<16>);
-        else rc = launch(k11_forest_lds<32>);
+        if (TH == 1024) {
+            if (fd.n_classes <= 4) rc = launch(k11_forest_lds<4, 1024>);
+            else if (fd.n_classes <= 8) rc = launch(k11_forest_lds<8, 1024>);
+            else if (fd.n_classes <= 16) rc = launch(k11_forest_lds<16, 1024>);
+            else rc = launch(k11_forest_lds<32, 1024>);
+        } else {
+            if (fd.n_classes <= 4) rc = launch(k11_forest_lds<4, 512>);
+            else if (fd.n_classes <= 8) rc = launch(k11_forest_lds<8, 512>);
+            else if (fd.n_classes <= 16) rc = launch(k11_forest_lds<16, 512>);
+            else if (fd.n_classes <= 32) rc = launch(k11_forest_lds<32, 512>);
+            else rc = launch(k11_forest_lds<64, 512>);
+        }
     } else {
         // a tree larger than the LDS area: the first ntop (breadth-first) nodes of RF_C trees in LDS, in steps of 256
-        int ntop = 3072;
-        while (ntop > 256 && (size_t)F * RF_TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node) > 158 * 1024) ntop -= 256;
-        const size_t lds = (size_t)F * RF_TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node);
+        int ntop = 3 * TH;
+        while (ntop > 256 && (size_t)F * TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node) > 158 * 1024) ntop -= 256;
+        const size_t lds = (size_t)F * TH * 4 + (size_t)RF_C * ntop * sizeof(rf_node);
         auto launch = [&](auto kern) -> int {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             prof_scope ps(ctx, "forest");
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(RF_TH), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees, fd.n_trees, ntop,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(TH), lds, ctx->stream, pl, F, n, (const rf_node *)fd.d_nodes, d_trees, fd.n_trees, ntop,
                                (const double *)fd.d_leafval, fd.n_classes, d_classes, (long long *)d_out);
             return RSSEG_OK;
         };
-        if (fd.n_classes <= 4) rc = launch(k11_forest_gen<4>);
-        else if (fd.n_classes <= 8) rc = launch(k11_forest_gen<8>);
-        else if (fd.n_classes <= 16) rc = launch(k11_forest_gen<16>);
-        else rc = launch(k11_forest_gen<32>);
+        if (TH == 1024) {
+            if (fd.n_classes <= 4) rc = launch(k11_forest_gen<4, 1024>);
+            else if (fd.n_classes <= 8) rc = launch(k11_forest_gen<8, 1024>);
+            else if (fd.n_classes <= 16) rc = launch(k11_forest_gen<16, 1024>);
+            else rc = launch(k11_forest_gen<32, 1024>);
+        } else {
+            if (fd.n_classes <= 4) rc = launch(k11_forest_gen<4, 512>);
+            else if (fd.n_classes <= 8) rc = launch(k11_forest_gen<8, 512>);
+            else if (fd.n_classes <= 16) rc = launch(k11_forest_gen<16, 512>);
+            else if (fd.n_classes <= 32) rc = launch(k11_forest_gen<32, 512>);
+            else rc = launch(k11_forest_gen<64, 512>);
+        }
     }
     if (rc != RSSEG_OK) return rc;
     HIPCHK(ctx, hipGetLastError());

@@ -20,12 +20,15 @@
 
 static inline unsigned k12_grid(int64_t n) { return (unsigned)std::min<int64_t>(65535 * 16, std::max<int64_t>(1, ceil_div64(n, K12_THREADS))); }
 
-// out = 1 where lo < x < hi (NaN counts as 0, extract.py:354-356); use -inf / +inf for one-sided thresholds
-__global__ __launch_bounds__(K12_THREADS) void k12_band(const float *__restrict__ x, int64_t n, float lo, float hi, uint8_t *__restrict__ out)
+// out = 1 where lo < x < hi; use -inf / +inf for one-sided thresholds.  nan_as_zero: threshold_segmentation's rule
+// (NaN -> 0 before the comparison, extract.py:354-356); otherwise a NaN pixel fails both comparisons, as the plain NumPy
+// comparisons of extract_bareland_by_rule do (extract.py:486-497)
+__global__ __launch_bounds__(K12_THREADS) void k12_band(const float *__restrict__ x, int64_t n, float lo, float hi, int nan_as_zero,
+                                                        uint8_t *__restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * K12_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * K12_THREADS) {
         float v = x[i];
-        if (v != v) v = 0.f;
+        if (nan_as_zero && v != v) v = 0.f;
         out[i] = (v > lo && v < hi) ? 1 : 0;
     }
 }
@@ -148,14 +151,19 @@ static int k12_check(rsseg_ctx *ctx, const char *what, const void *a, const void
     return RSSEG_OK;
 }
 
-extern "C" int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, uint8_t *d_out)
+extern "C" int rsseg_band_interval_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, int nan_as_zero, uint8_t *d_out)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_x || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "threshold: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (n) hipLaunchKernelGGL(k12_band, dim3(k12_grid(n)), dim3(K12_THREADS), 0, ctx->stream, d_x, n, lo, hi, d_out);
+    if (n) hipLaunchKernelGGL(k12_band, dim3(k12_grid(n)), dim3(K12_THREADS), 0, ctx->stream, d_x, n, lo, hi, nan_as_zero, d_out);
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);
+}
+
+extern "C" int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, uint8_t *d_out)
+{
+    return rsseg_band_interval_f32(ctx, d_x, n, lo, hi, 1, d_out);
 }
 
 extern "C" int rsseg_mask_op_u8(rsseg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int64_t n, int op, uint8_t *d_out)

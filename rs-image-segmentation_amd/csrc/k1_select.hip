@@ -6,6 +6,8 @@
 // builds LDS-private histograms per workgroup (one 2048-bin table per distinct key prefix still
 // alive) and flushes the non-zero bins to HBM with 64-bit atomics.  HBM-bound: 12 B/px for any
 // number of ranks <= RSSEG_MAX_RANKS.
+#include <mutex>
+
 #include "common.h"
 
 #define SEL_BINS 2048
@@ -188,7 +190,9 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes may need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
 
     static bool attr_done[64] = {false};  // hipFuncSetAttribute is per device
+    static std::mutex attr_mu;            // contexts of several threads (one per rank in the threaded tests) may arrive together
     const int SEL_BATCH = 8;  // live prefixes per launch: 8 * (8 KB counters + 2 KB lookup) + 2 KB of LDS
+    std::unique_lock<std::mutex> attr_lock(attr_mu);
     if (!attr_done[ctx->device & 63]) {
         const int l1 = SEL_BATCH * SEL_BINS * 4 + SEL_BINS, l2 = SEL_BATCH * SEL_BINS * 5 + SEL_BINS, l0 = P0_COPIES * P0_STRIDE * 4;
 #define SEL_ATTR(TH)                                                                                                       \
@@ -199,6 +203,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         SEL_ATTR(1024)
         attr_done[ctx->device & 63] = true;
     }
+    attr_lock.unlock();
     const int threads = 1024;
     const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
     auto launch = [&](const float *d_x, int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb, unsigned long long *d_nan) {

@@ -24,6 +24,8 @@
 //        size, levels <= 64; the reference's 21x21 / step 21 default).
 #include <utility>
 
+#include <mutex>
+
 #include "common.h"
 
 __constant__ long long c_glcm_hq[256];
@@ -867,7 +869,8 @@ __global__ __launch_bounds__(256) void k4_glcm_wg(const uint8_t *__restrict__ q,
     }
 }
 
-static bool g_hq_ready[64] = {false};
+static bool g_hq_ready[64] = {false};   // per device: the homogeneity tables are in place
+static std::mutex g_hq_mu;              // contexts of several threads may arrive together
 
 extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int levels, int win, int step,
                              float *const *d_props)
@@ -876,15 +879,17 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
     if (!d_q || !d_props || H < 1 || W < 1 || levels < 2 || levels > 256 || win < 2 || win > H || win > W || step < 1)
         return rs_fail(ctx, RSSEG_ERR_INVALID, "glcm: bad arguments (H=%d W=%d levels=%d win=%d step=%d)", H, W, levels, win, step);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::unique_lock<std::mutex> hq_lock(g_hq_mu);
     if (!g_hq_ready[ctx->device & 63]) {
         long long lut[256];
         for (int d = 0; d < 256; d++) lut[d] = llrint(4503599627370496.0 / (1.0 + (double)d * (double)d));
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_glcm_hq), lut, sizeof(lut)));
-        static long long lut2[1024];
+        long long lut2[1024];
         for (int i = 0; i < 1024; i++) lut2[i] = lut[i & 31] + lut[i >> 5];
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_glcm_hq2), lut2, sizeof(lut2)));
         g_hq_ready[ctx->device & 63] = true;
     }
+    hq_lock.unlock();
     const int oh = (H - win) / step + 1, ow = (W - win) / step + 1;
     glcm_out out;
     for (int i = 0; i < 5; i++) out.p[i] = d_props[i];

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_sample(planes_t pl, int F, 
 //            Integer adds commute, so the result is independent of any order.
 // LDS: 32 accumulator copies only (33 KB at KMAX = 8, F <= 15).
 // ------------------------------------------------------------------------------------------------
+static_assert(RSSEG_MAX_FEATURES <= 64, "km_gather_row / km_kpp_sample give one of their first 64 threads to each feature");
 #define KM_COPIES 32
 __host__ __device__ inline int km_copy_stride(int KMAX, int F)
 {
@@ -596,6 +598,297 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
 #pragma unroll
                         for (int p = 0; p < PXL; p++)
                             if (valid[p]) atomicAdd(&myS[lab[p] * F + f], (unsigned long long)q[p]);
+                    }
+                }
+            }
+        }
+    };
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t tbase = chunk0 + (int64_t)t * TILE;
+        if (tbase >= n) break;
+        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+        if (tbase + TILE <= n) tile_body(std::true_type{}, base);
+        else tile_body(std::false_type{}, base);
+    }
+    if (UPDATE) {
+        int ch = wave_sum(my_changed);
+        __shared__ int changed_w[4];
+        if (lane == 0) changed_w[threadIdx.x >> 6] = ch;
+        __syncthreads();
+        const int M = KMAX * F + KMAX + 1;
+        for (int i = threadIdx.x; i < M; i += KM_THREADS) {
+            long long v;
+            if (i < KMAX * F + KMAX) {
+                unsigned long long a = 0;
+                for (int c = 0; c < ncopies; c++) a += S[(size_t)c * stride + i];
+                v = (long long)a;
+            } else {
+                v = changed_w[0] + changed_w[1] + changed_w[2] + changed_w[3];
+            }
+            partial[(size_t)i * nchunks + blockIdx.x] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature-BLOCKED forms for 32 < F <= RSSEG_MAX_FEATURES (the reference's default key selection clusters every 2-D
+// plane of the stage-2 dictionary: 55 planes, extract.py:516-522).  F register-resident planes per lane do not fit
+// any more, so a tile walks the planes in blocks of KM_FB: the k dot products (and the k-means++ sums) are carried
+// across the blocks in the same per-feature fma order as the register-resident kernels — same bits — and the Lloyd
+// update re-reads the blocks after the argmin (the second read of a tile comes from the L2: 2 x 4F B/px requested,
+// not an HBM-bound path any more but the same arithmetic).
+// ------------------------------------------------------------------------------------------------
+#define KM_FB 16
+
+template <typename T, bool FULL>
+__device__ __forceinline__ void load_block(const planes_t &pl, int F, int f0, int64_t base, int64_t n, T (&x)[KM_FB][vt<T>::PXL])
+{
+#pragma unroll
+    for (int j = 0; j < KM_FB; j++) {
+        if (f0 + j < F) load_pxf<T, FULL>(pl.p[f0 + j], base, n, x[j]);
+        else {
+#pragma unroll
+            for (int p = 0; p < vt<T>::PXL; p++) x[j][p] = (T)0;
+        }
+    }
+}
+
+// np.var numerators of one plane per workgroup row (grid: nchunks x F): partial[(1 + f) * nchunks + chunk], the rows
+// km_kpp<MODE 0> fills for F <= 32
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void km_var(planes_t pl, int64_t n, const scaler_t<T> *__restrict__ sp,
+                                                     unsigned long long *__restrict__ partial, int64_t nchunks)
+{
+    constexpr int PXL = vt<T>::PXL;
+    const int f = blockIdx.y;
+    const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    long long acc = 0;
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t base = chunk0 + (int64_t)t * km_tile<T>() + (int64_t)threadIdx.x * PXL;
+        if (base >= n) break;
+        T v[PXL];
+        load_px<T>(pl.p[f], base, n, v);
+#pragma unroll
+        for (int i = 0; i < PXL; i++)
+            if (base + i < n) {
+                const T yt = scaled<T>(v[i], sc, mnv) - me;
+                const T dd = yt * yt;
+                acc += to_fixed40((double)dd);
+            }
+    }
+    acc = wave_sum(acc);
+    __shared__ long long sacc[4];
+    if (lane_id() == 0) sacc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)(1 + f) * nchunks + blockIdx.x] = (unsigned long long)(sacc[0] + sacc[1] + sacc[2] + sacc[3]);
+}
+
+// km_kpp for F > 32 (MODE 0 without the variance rows: km_var writes them)
+template <typename T, int NL, int MODE>
+__global__ __launch_bounds__(KM_THREADS) void km_kpp_blk(planes_t pl, int F, int64_t n, const scaler_t<T> *__restrict__ sp,
+                                                         const double *__restrict__ candT, const double *__restrict__ cc, int L,
+                                                         T *__restrict__ closest, unsigned long long *__restrict__ partial, int64_t nchunks)
+{
+    constexpr int PXL = vt<T>::PXL;
+    unsigned long long acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) acc[l] = 0;
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    auto tile_body = [&](auto full_t, int64_t base) {
+        constexpr bool FULL = decltype(full_t)::value;
+        T cl[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) cl[p] = (T)0;
+        if constexpr (MODE == 2) load_pxf<T, FULL>(closest, base, n, cl);
+        double dot[NL][PXL], dotp[PXL], yy[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            yy[p] = 0.0;
+            dotp[p] = 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; l++) dot[l][p] = 0.0;
+        }
+        for (int f0 = 0; f0 < F; f0 += KM_FB) {
+            T x[KM_FB][PXL];
+            load_block<T, FULL>(pl, F, f0, base, n, x);
+#pragma unroll
+            for (int j = 0; j < KM_FB; j++) {
+                const int f = f0 + j;
+                if (f < F) {
+                    const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+                    double cd[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) cd[l] = candT[f * KPP_STRIDE + l];
+                    const double cdp = candT[f * KPP_STRIDE + KPP_MAXL];
+#pragma unroll
+                    for (int p = 0; p < PXL; p++) {
+                        const T yt = scaled<T>(x[j][p], sc, mnv) - me;
+                        const double y = (double)yt;
+                        yy[p] = fma(y, y, yy[p]);
+                        if constexpr (MODE != 0) dotp[p] = fma(cdp, y, dotp[p]);
+#pragma unroll
+                        for (int l = 0; l < NL; l++) dot[l][p] = fma(cd[l], y, dot[l][p]);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE != 0) {
+            const double ccp = cc[KPP_MAXL];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) {
+                double d = -2.0 * dotp[p];
+                d = d + ccp;
+                d = d + yy[p];
+                T dt = (T)d;
+                dt = dt > (T)0 ? dt : (T)0;
+                if constexpr (MODE == 2) dt = cl[p] < dt ? cl[p] : dt;
+                cl[p] = dt;
+            }
+            if (FULL || base + PXL <= n) {
+                typename vt<T>::vec o;
+                if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                else o = make_double2(cl[0], cl[1]);
+                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+            } else {
+                for (int p = 0; p < PXL; p++)
+                    if (base + p < n) closest[base + p] = cl[p];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            if (l < L) {
+                const double ccl = cc[l];
+#pragma unroll
+                for (int p = 0; p < PXL; p++) {
+                    double d = -2.0 * dot[l][p];
+                    d = d + ccl;
+                    d = d + yy[p];
+                    T dt = (T)d;
+                    dt = dt > (T)0 ? dt : (T)0;
+                    if constexpr (MODE != 0) dt = cl[p] < dt ? cl[p] : dt;
+                    if (FULL || base + p < n) acc[l] += (unsigned long long)to_fixed40((double)dt);
+                }
+            }
+        }
+    };
+    for (int t = 0; t < KM_TILES_PER_CHUNK; t++) {
+        const int64_t tbase = chunk0 + (int64_t)t * km_tile<T>();
+        if (tbase >= n) break;
+        const int64_t base = tbase + (int64_t)threadIdx.x * PXL;
+        if (tbase + km_tile<T>() <= n) tile_body(std::true_type{}, base);
+        else tile_body(std::false_type{}, base);
+    }
+    __shared__ unsigned long long sacc[4][NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        unsigned long long s = wave_sum(acc[l]);
+        if (lane_id() == 0) sacc[threadIdx.x >> 6][l] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NL && (int)threadIdx.x < L)
+        partial[(size_t)threadIdx.x * nchunks + blockIdx.x] =
+            sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x];
+}
+
+// km_lloyd for F > 32: same partial layout, same LDS accumulators
+template <typename T, int KMAX, bool UPDATE>
+__global__ __launch_bounds__(KM_THREADS) void km_lloyd_blk(planes_t pl, int F, int k, int64_t n,
+                                                           const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
+                                                           const T *__restrict__ csq, uint8_t *__restrict__ labels,
+                                                           long long *__restrict__ partial, int64_t nchunks, int ncopies)
+{
+    constexpr int PXL = vt<T>::PXL;
+    constexpr int TILE = KM_THREADS * PXL;
+    extern __shared__ __align__(16) char smem[];
+    unsigned long long *S = reinterpret_cast<unsigned long long *>(smem);
+    const int stride = km_copy_stride(KMAX, F);
+    const int lane = threadIdx.x & 63;
+    unsigned long long *myS = S + (size_t)(lane & (ncopies - 1)) * stride;
+    if (UPDATE) {
+        for (int i = threadIdx.x; i < ncopies * stride; i += KM_THREADS) S[i] = 0ull;
+        __syncthreads();
+    }
+    const int64_t chunk0 = (int64_t)blockIdx.x * km_chunk<T>();
+    int my_changed = 0;
+    auto tile_body = [&](auto full_t, int64_t base) {
+        constexpr bool FULL = decltype(full_t)::value;
+        T acc[KMAX][PXL];
+#pragma unroll
+        for (int j = 0; j < KMAX; j++)
+#pragma unroll
+            for (int p = 0; p < PXL; p++) acc[j][p] = (T)0;
+        for (int f0 = 0; f0 < F; f0 += KM_FB) {
+            T x[KM_FB][PXL];
+            load_block<T, FULL>(pl, F, f0, base, n, x);
+#pragma unroll
+            for (int jf = 0; jf < KM_FB; jf++) {
+                const int f = f0 + jf;
+                if (f < F) {
+                    const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+#pragma unroll
+                    for (int p = 0; p < PXL; p++) x[jf][p] = scaled<T>(x[jf][p], sc, mnv) - me;
+#pragma unroll
+                    for (int j = 0; j < KMAX; j++) {
+                        const T cj = cenT[f * KMAX + j];
+#pragma unroll
+                        for (int p = 0; p < PXL; p++) acc[j][p] = tfma<T>(x[jf][p], cj, acc[j][p]);
+                    }
+                }
+            }
+        }
+        int lab[PXL];
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            T bd = tfma<T>((T)-2, acc[0][p], csq[0]);
+            int bl = 0;
+#pragma unroll
+            for (int j = 1; j < KMAX; j++) {
+                if (j < k) {
+                    T d = tfma<T>((T)-2, acc[j][p], csq[j]);
+                    if (d < bd) { bd = d; bl = j; }
+                }
+            }
+            lab[p] = bl;
+        }
+        if (FULL || base + PXL <= n) {
+            if constexpr (PXL == 4) {
+                uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
+                my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
+                *reinterpret_cast<uchar4 *>(labels + base) = make_uchar4(lab[0], lab[1], lab[2], lab[3]);
+            } else {
+                uchar2 old = *reinterpret_cast<const uchar2 *>(labels + base);
+                my_changed += (old.x != lab[0]) + (old.y != lab[1]);
+                *reinterpret_cast<uchar2 *>(labels + base) = make_uchar2(lab[0], lab[1]);
+            }
+        } else {
+            for (int p = 0; p < PXL; p++)
+                if (base + p < n) {
+                    my_changed += labels[base + p] != lab[p];
+                    labels[base + p] = (uint8_t)lab[p];
+                }
+        }
+        if (UPDATE) {
+            bool valid[PXL];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) valid[p] = FULL || base + p < n;
+#pragma unroll
+            for (int p = 0; p < PXL; p++)
+                if (valid[p]) atomicAdd(&myS[KMAX * F + lab[p]], 1ull);
+            for (int f0 = 0; f0 < F; f0 += KM_FB) {
+                T x[KM_FB][PXL];
+                load_block<T, FULL>(pl, F, f0, base, n, x);
+#pragma unroll
+                for (int jf = 0; jf < KM_FB; jf++) {
+                    const int f = f0 + jf;
+                    if (f < F) {
+                        const T sc = sp->scale[f], mnv = sp->minv[f], me = sp->mean[f];
+#pragma unroll
+                        for (int p = 0; p < PXL; p++)
+                            if (valid[p]) {
+                                const T xv = scaled<T>(x[jf][p], sc, mnv) - me;
+                                atomicAdd(&myS[lab[p] * F + f], (unsigned long long)to_fixed40((double)xv));
+                            }
                     }
                 }
             }
@@ -881,12 +1174,17 @@ int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plan
                   const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
 {
     if (update) {
-        static size_t attr[64] = {0};  // per device: the dynamic-LDS limit already granted to this instantiation
-        size_t &have = attr[ctx->device & 63];
-        if (have == 0) have = 48 * 1024;  // default limit without the attribute
-        if (lds > have) {
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, FR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            have = lds;
+        // per device: the dynamic-LDS limit already granted to this instantiation (contexts of several threads may race here)
+        static std::mutex mu;
+        static size_t attr[64] = {0};
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t &have = attr[ctx->device & 63];
+            if (have == 0) have = 48 * 1024;  // default limit without the attribute
+            if (lds > have) {
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd<T, KMAX, FR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                have = lds;
+            }
         }
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
                            cenT, csq, labels, partial, nchunks, ncopies);
@@ -903,7 +1201,27 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
 {
     if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
     if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
-    return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
+    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
+    // 32 < F <= RSSEG_MAX_FEATURES: the feature-blocked kernel
+    if (update) {
+        static std::mutex mu;
+        static size_t attr[64] = {0};
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t &have = attr[ctx->device & 63];
+            if (have == 0) have = 48 * 1024;
+            if (lds > have) {
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)km_lloyd_blk<T, KMAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                have = lds;
+            }
+        }
+        hipLaunchKernelGGL((km_lloyd_blk<T, KMAX, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
+                           cenT, csq, labels, partial, nchunks, ncopies);
+    } else {
+        hipLaunchKernelGGL((km_lloyd_blk<T, KMAX, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
+                           cenT, csq, labels, partial, nchunks, ncopies);
+    }
+    return RSSEG_OK;
 }
 
 template <typename T, int NL, int FR>
@@ -925,7 +1243,18 @@ void launch_kpp2(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_t n,
 {
     if (F <= 8) launch_kpp3<T, NL, 8>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
     else if (F <= 16) launch_kpp3<T, NL, 16>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
-    else launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
+    else if (F <= 32) launch_kpp3<T, NL, 32>(ctx, nchunks, pl, F, n, sp, cand, cc, L, mode, closest, partial);
+    else {   // feature-blocked kernels; the variance rows of the first pass come from km_var
+#define KPP_GOB(M) hipLaunchKernelGGL((km_kpp_blk<T, NL, M>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, sp, cand, cc, L, closest, partial, nchunks)
+        if constexpr (NL == 1) {
+            KPP_GOB(0);
+            hipLaunchKernelGGL((km_var<T>), dim3((unsigned)nchunks, F), dim3(KM_THREADS), 0, ctx->stream, pl, n, sp, partial, nchunks);
+        } else {
+            if (mode == 1) KPP_GOB(1);
+            else KPP_GOB(2);
+        }
+#undef KPP_GOB
+    }
 }
 // mode 0: first centre (L == 1, no per-pixel output); 1: first sampling round; 2: later rounds
 template <typename T>
@@ -943,7 +1272,8 @@ void launch_farthest(rsseg_ctx *ctx, int64_t nchunks, planes_t pl, int F, int64_
 {
     if (F <= 8) hipLaunchKernelGGL((km_farthest<T, KMAX, 8>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
     else if (F <= 16) hipLaunchKernelGGL((km_farthest<T, KMAX, 16>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
-    else hipLaunchKernelGGL((km_farthest<T, KMAX, 32>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
+    else if (F <= 32) hipLaunchKernelGGL((km_farthest<T, KMAX, 32>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
+    else hipLaunchKernelGGL((km_farthest<T, KMAX, 64>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, n, offset, sp, cenT, labels, tk, pdist, pidx);
 }
 
 template <typename T>
@@ -988,7 +1318,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     // small host-to-device uploads (candidate rows, centres) go through a ring of pinned slots behind the read-back area:
     // the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came from dies
     // (a slot is reused four uploads later; every k-means++ round and every Lloyd iteration synchronises in between)
-    constexpr size_t UP_SLOT = 32 * 1024;
+    constexpr size_t UP_SLOT = 64 * 1024;
     const size_t pin_main = (pin_need + 255) & ~(size_t)255;
     RSCHK(pin_reserve(ctx, pin_main + 4 * UP_SLOT));
     unsigned up_i = 0;
@@ -1315,7 +1645,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         // potentials of all L candidates with ONE all-reduce: slot [l][rank] = this rank's chunk-sum total
         u128 rt_all[KPP_MAXL][RSSEG_MAX_RANKS], tot_all[KPP_MAXL];
         {
-            static long long lim[2 * KPP_MAXL * RSSEG_MAX_RANKS];
+            long long lim[2 * KPP_MAXL * RSSEG_MAX_RANKS];   // per call: contexts of several threads run this function concurrently
             memset(lim, 0, sizeof(lim));
             for (int l = 0; l < L; l++) {
                 u128 loc = 0;
@@ -1558,8 +1888,11 @@ static int kmeans_entry(rsseg_ctx *ctx, const void *const *d_planes, int F, int 
                         const double *local_max)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_planes || F < 1 || F > RSSEG_MAX_FEATURES) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: F=%d outside [1,%d]", F, RSSEG_MAX_FEATURES);
-    if (k < 1 || k > RSSEG_MAX_CLUSTERS) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_clusters=%d outside [1,%d]", k, RSSEG_MAX_CLUSTERS);
+    if (!d_planes || F < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: no feature planes");
+    if (k < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: n_clusters=%d must be >= 1", k);
+    // capacities of the kernels, not limits of the reference: reported as UNSUPPORTED (never as an empty result)
+    if (F > RSSEG_MAX_FEATURES) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: %d feature planes, the kernels take at most %d", F, RSSEG_MAX_FEATURES);
+    if (k > RSSEG_MAX_CLUSTERS) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: n_clusters=%d, the kernels take at most %d", k, RSSEG_MAX_CLUSTERS);
     if (n_local < 0 || (n_local > 0 && !d_labels)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: bad n_local / labels");
     if (max_iter < 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: max_iter must be >= 1");
     if (dtype != RSSEG_F32 && dtype != RSSEG_F64) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: dtype must be RSSEG_F32 or RSSEG_F64");

@@ -284,7 +284,7 @@ def extract_bareland_by_rule(features_dict, vegetation_mask, water_mask, builtup
     for key, lo, hi in (("ndvi", ndvi_low_threshold, ndvi_high_threshold), ("ndbi", ndbi_low_threshold, ndbi_high_threshold)):
         d = _f32(features_dict, key, (h, w))
         if d is not None:
-            m = ctx.mask_op(m, ctx.threshold_band(d, float(np.float32(lo)), float(np.float32(hi))), L.MASK_AND)
+            m = ctx.mask_op(m, ctx.threshold_band(d, float(np.float32(lo)), float(np.float32(hi)), nan_as_zero=False), L.MASK_AND)  # NaN: False
     if post_process:
         m = _post(ctx, m, h, w, min_area, 3)
     return m.cpu().numpy().reshape(h, w)
@@ -324,7 +324,7 @@ def rule_based_classification(features):
     bare = ctx.mask_op(final, None, L.MASK_NOT)                                         # final == 0
     for d, lo, hi in ((ndvi, -0.1, 0.2), (ndbi, -0.2, 0.2)):
         if d is not None:
-            bare = ctx.mask_op(bare, ctx.threshold_band(d, float(np.float32(lo)), float(np.float32(hi))), L.MASK_AND)
+            bare = ctx.mask_op(bare, ctx.threshold_band(d, float(np.float32(lo)), float(np.float32(hi)), nan_as_zero=False), L.MASK_AND)  # extract.py:486-497
     bare = _post(ctx, bare, h, w, int(n * 0.0005), 3)
     ctx.mask_paint(final, bare, 4, only_unset=True)
     return final.cpu().numpy().reshape(h, w)

@@ -2,13 +2,16 @@
 Drop-in counterpart of predict_image of the reference's modules/supervised_classifiers.py:99-115: a
 fitted sklearn RandomForestClassifier (or an already flattened forest dict) applied to every pixel of an
 (H, W, D) feature array by the K11 forest-walk kernel.  Like the reference, any failure is reported and
-answered with an all-zero map (supervised_classifiers.py:113-115).
+answered with an all-zero map (supervised_classifiers.py:113-115) — except a forest beyond the capacity of the
+kernels (more than 64 features or classes): that is this library's limit, not a failure the reference would have had,
+and raises rsseg.runtime.RssegUnsupported instead of returning an empty map.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from rsseg.forest import flatten_forest
+from rsseg.runtime import RssegUnsupported
 from rsseg.runtime import default_context as _ctx
 
 __all__ = ["predict_image", "np"]
@@ -28,6 +31,8 @@ def predict_image(model, features):
         h, w, d = features.shape
         planes = [features[:, :, i] for i in range(d)]
         return _predict_planes(model, planes).reshape(h, w)
+    except RssegUnsupported:
+        raise
     except Exception as e:  # noqa: BLE001 — reference behaviour
         print("❌ 预测失败:", e)
         return np.zeros(features.shape[:2], dtype=int)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "librsseg_hip.so")
 
-MAX_FEATURES = 32
+MAX_FEATURES = 64
 MAX_CLUSTERS = 64
 MAX_RANKS = 16
 F32, F64, I64 = 0, 1, 2
@@ -97,6 +97,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_double), _int, C.POINTER(_i64), _int]),
     "rsseg_forest_predict": (_int, [_vp, _PP, _int, _i64, _vp]),
     "rsseg_threshold_band_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
+    "rsseg_band_interval_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _int, _vp]),
     "rsseg_mask_op_u8": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "rsseg_mask_paint_u8": (_int, [_vp, _vp, _vp, _i64, _int, _int]),
     "rsseg_morph_ellipse_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),

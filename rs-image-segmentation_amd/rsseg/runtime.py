@@ -19,6 +19,11 @@ class RssegError(RuntimeError):
     pass
 
 
+class RssegUnsupported(RssegError):
+    """RSSEG_ERR_UNSUPPORTED: a valid input beyond a capacity of the kernels (more than 64 features / classes, ...).
+    Never swallowed by the mirrors: the reference would have produced a result, so an all-zero map would be a lie."""
+
+
 def _torch():
     import torch
     return torch
@@ -169,6 +174,8 @@ class Context:
                 raise ValueError(msg)
             if rc == -3:
                 raise MemoryError(msg)
+            if rc == -5:
+                raise RssegUnsupported(msg)
             raise RssegError(f"rsseg error {rc}: {msg}")
 
     # ---- buffers --------------------------------------------------------------------------------
@@ -183,7 +190,10 @@ class Context:
         torch = _torch()
         a = np.ascontiguousarray(a).reshape(-1)
         if a.dtype == np.uint8:
-            return torch.from_numpy(a).to(self.device).to(torch.float32)
+            # the widening is a device kernel: it runs on THIS context's stream, where the library's kernels that read
+            # the plane are enqueued (a context may own a side stream that is not torch's current stream)
+            with torch.cuda.stream(self.torch_stream):
+                return torch.from_numpy(a).to(self.device).to(torch.float32)
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     def empty(self, n, dtype):
@@ -440,12 +450,13 @@ class Context:
         return out
 
     # ---- K12: rule-based classification -------------------------------------------------------
-    def threshold_band(self, plane, lo: float = float("-inf"), hi: float = float("inf")):
-        """uint8 mask: 1 where lo < x < hi (NaN counts as 0)."""
+    def threshold_band(self, plane, lo: float = float("-inf"), hi: float = float("inf"), nan_as_zero: bool = True):
+        """uint8 mask: 1 where lo < x < hi.  nan_as_zero: NaN counts as 0 (threshold_segmentation, extract.py:354-356);
+        False: a NaN pixel is outside every interval (the plain comparisons of extract_bareland_by_rule, extract.py:486-497)."""
         torch = _torch()
         out = self.empty(plane.numel(), torch.uint8)
-        self._chk(self.lib.rsseg_threshold_band_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo), C.c_float(hi),
-                                                    C.c_void_p(out.data_ptr())))
+        self._chk(self.lib.rsseg_band_interval_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo), C.c_float(hi),
+                                                   int(nan_as_zero), C.c_void_p(out.data_ptr())))
         return out
 
     def mask_op(self, a, b, op: int):

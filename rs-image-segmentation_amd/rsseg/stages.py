@@ -34,28 +34,35 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     def host(t):
         return t.cpu().numpy().reshape(h, w)
 
+    # features_dict in the reference's insertion order (scripts/2:62-106; the members of the nested dicts in the order
+    # indices.py builds them): the order is part of the interface, because unsupervised_kmeans_classification's default
+    # key selection stacks the 2-D members in dict order (extract.py:516-522, 568)
+    from . import _lib as L
     fd: Dict[str, object] = {k: host(v) for k, v in ex["indices"].items()}
     fd["pca_result"] = [host(p) for p in ex["pca"]]
     fd["variance_ratio"] = ex["pca_ratio"]
     fd["glcm_features"] = {k: host(v) for k, v in ex["glcm"].items()}
-    # the window-operator members of the dict (indices.py:320-344, 401-482, 519-562) beyond the three the stack consumes
-    from . import _lib as L
     nir2, q255 = ex["nir2"], ex["q255"]  # the re-normalised NIR band and its uint8 image (indices.py:412-415)
+    lbp = ctx.lbp_uniform(q255, h, w, 24, 3).cpu().numpy().reshape(h, w).astype(np.float64)
+    fd["lbp_feature"] = lbp / lbp.max()
+    ms: Dict[str, np.ndarray] = {}
+    for k in (1, 3, 5, 7):                # per scale: mean, variance, std_dev, entropy for scales <= 5 (indices.py:535-560)
+        if k == 1:                        # cv2.blur with a 1 x 1 kernel is the identity: variance and std are exactly 0
+            ms["mean_scale_1"] = host(nir2)
+            ms["variance_scale_1"] = np.zeros((h, w), np.float32)
+            ms["std_dev_scale_1"] = np.zeros((h, w), np.float32)
+        else:
+            ms[f"mean_scale_{k}"] = host(ctx.box_mean(nir2, h, w, k, L.BORDER_REFLECT101))
+            ms[f"variance_scale_{k}"] = host(ctx.local_var(nir2, h, w, k))
+            ms[f"std_dev_scale_{k}"] = host(planes[17]) if k == 5 else host(ctx.local_std(nir2, h, w, k))
+        if k <= 5:
+            e = ctx.rank_entropy(q255, h, w, k).cpu().numpy().reshape(h, w)
+            ms[f"entropy_scale_{k}"] = e / np.max(e)
+    fd["multi_scale_features"] = ms
     ops = (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE),
            ("gradient", L.MORPH_GRADIENT))
     fd["morphological_features"] = {f"{name}_{k}": ctx.morph(q255, h, w, k, op).cpu().numpy().reshape(h, w) / 255.0
                                     for k in (3, 5, 7) for name, op in ops}
-    ms = {"mean_scale_1": host(nir2), "variance_scale_1": np.zeros((h, w), np.float32), "std_dev_scale_1": np.zeros((h, w), np.float32)}
-    for k in (3, 5, 7):
-        ms[f"mean_scale_{k}"] = host(ctx.box_mean(nir2, h, w, k, L.BORDER_REFLECT101))
-        ms[f"variance_scale_{k}"] = host(ctx.local_var(nir2, h, w, k))
-        ms[f"std_dev_scale_{k}"] = host(planes[17]) if k == 5 else host(ctx.local_std(nir2, h, w, k))
-    for k in (1, 3, 5):
-        e = ctx.rank_entropy(q255, h, w, k).cpu().numpy().reshape(h, w)
-        ms[f"entropy_scale_{k}"] = e / np.max(e)
-    fd["multi_scale_features"] = ms
-    lbp = ctx.lbp_uniform(q255, h, w, 24, 3).cpu().numpy().reshape(h, w).astype(np.float64)
-    fd["lbp_feature"] = lbp / lbp.max()
     g5 = ctx.gaussian_blur_u8(q255, h, w, 5).cpu().numpy().reshape(h, w) / 255.0
     g15 = ctx.gaussian_blur_u8(q255, h, w, 15).cpu().numpy().reshape(h, w) / 255.0
     dog = g5 - g15
@@ -132,47 +139,168 @@ def run_kmeans_stage(hierarchical_all: np.ndarray, n_clusters: int = 7, ctx: Opt
     return (labels.cpu().numpy().reshape(h, w) + 1).astype(np.uint8)
 
 
-def run_classification_stage(features_filepath: str, method: str = "kmeans", output_dir: str = "output", n_clusters: int = 7,
-                             classifier=None, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
-    """run_classification_stage (scripts/3_classification.py:267-505) on a feature file written by stage 2:
-    method 'rule_based' (thresholds + morphology + area filter, scripts/3:335-375), 'kmeans' (:377-398) or
-    'random_forest' / 'rf' / 'supervised' (:401-488, with a fitted classifier passed in: training is out of scope).
-    The shipped script filters the normalised dict with un-prefixed key names (scripts/3:381-383) which never match stage
-    2's layout (SURVEY.md 3.2); this driver passes the keys that do exist ('hierarchical_features_all' for the
-    clusterer / forest, 'all_extracted_features_dict_<index>' for the rules).
+RF_MODEL_FILE = "random_forest_model.joblib"   # scripts/3_classification.py:459
+
+
+def run_classification_stage(feature_file_path, method='rule_based', output_dir="segmentation_outputs", use_hierarchical_all=True, *,
+                             n_clusters: int = 7, classifier=None, feature_keys=None, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
+    """run_classification_stage (scripts/3_classification.py:267-505): the reference's name, positional order and defaults
+    (`method='rule_based'`, `output_dir="segmentation_outputs"`, `use_hierarchical_all=True`); what follows the `*` are
+    keyword-only additions.  Loads and normalises the feature file (extract.py:32-295), dispatches on `method`:
+
+      'rule_based'     thresholds + morphology + area filter (scripts/3:335-375).  The rules read 'ndvi', 'ndwi', 'mndwi',
+                       'ndbi' (extract.py:406-505); stage 2's pickle stores them under 'all_extracted_features_dict_<index>'
+                       after normalisation, and those are used when the plain keys are absent.
+      'kmeans'         scripts/3:377-398: the keys ['ndvi', 'ndwi', 'ndbi', 'texture_mean', 'hierarchical_all'] that exist, 7
+                       clusters (`n_clusters`), labels + 1.  On a stage-2 pickle none of them exists (the keys are prefixed,
+                       SURVEY.md 3.2); the reference then announces "将使用自动选择" (automatic selection) but hands over the
+                       EMPTY list, on which unsupervised_kmeans_classification raises (extract.py:533).  This driver does what
+                       the message says: `feature_keys_to_use=None`, i.e. every 2-D plane of the dictionary (55 on a stage-2
+                       pickle).  `feature_keys` overrides the selection.
+      'random_forest'  scripts/3:401-488, inference part: the feature array is 'hierarchical_all' (also under stage 2's key
+                       'hierarchical_features_all') when `use_hierarchical_all`, else every 2-D plane of the image's shape
+                       stacked (:425-437); the classifier is `classifier` when given, else <output_dir>/random_forest_model.joblib
+                       when it exists and its n_features_in_ matches (:459-475).  Training (prepare_training_samples +
+                       train_random_forest_classifier, :450-475) is outside the hot path: without a usable model the stage reports
+                       that and returns None.
+
     Writes <output_dir>/classification_<method>.npy and, when the feature file carries transform / crs / width / height
-    (scripts/3:495-498), <output_dir>/<method>_classification_map.tif (uint8 labels, nodata 0, LZW tiles).  Returns the
-    label map (KMeans labels start at 1, scripts/3:394); None when the features are missing."""
+    (scripts/3:495-498), <output_dir>/<method>_classification_map.tif (uint8 labels, nodata 0, LZW tiles); the PNG of
+    scripts/3:491 is plotting (out of scope).  The reference returns None; this returns the label map as well (None on the
+    reference's error paths, which print and return)."""
     from modules.features.extract import load_features, normalize_features_structure, unsupervised_kmeans_classification
-    feats = normalize_features_structure(load_features(features_filepath))
-    key = "hierarchical_features_all"
     os.makedirs(output_dir, exist_ok=True)
+    try:
+        raw = load_features(feature_file_path)
+        if not raw:
+            print("加载原始特征失败。")
+            return None
+        feats = normalize_features_structure(raw)
+        skip = ("transform", "crs", "width", "height", "dimensions", "geo_transform", "hierarchical_level_1", "hierarchical_level_2",
+                "hierarchical_all")
+        has_arrays = any(isinstance(v, np.ndarray) and v.ndim >= 2 for k, v in feats.items() if k not in skip)
+        has_all = isinstance(feats.get("hierarchical_all"), np.ndarray) and feats["hierarchical_all"].ndim == 3
+        has_dims = isinstance(feats.get("height"), int) and isinstance(feats.get("width"), int)
+        if not (has_arrays or has_all) or not has_dims:
+            print("错误：规范化后的特征不包含有效的图像数组数据（单个特征或hierarchical_all）或尺寸信息。")
+            print(f"规范化后的键: {list(feats.keys())}")
+            return None
+    except Exception as e:  # noqa: BLE001 — scripts/3:307-311 prints and returns
+        print(f"加载或规范化特征失败: {e}")
+        return None
+    shape = (feats["height"], feats["width"])
+    if ctx is not None:   # the mirrors run on the process-wide context
+        from . import runtime as _rt
+        _rt._default_ctx = ctx
     if method == "rule_based":
         from modules.features.extract import rule_based_classification
-        idx = {k: feats.get(f"all_extracted_features_dict_{k}") for k in ("ndvi", "ndwi", "mndwi", "ndbi")}
-        if idx["ndvi"] is None:
-            print(f"特征 'ndvi' 不存在: {list(feats.keys())}")
-            return None
-        rules = {k: v for k, v in idx.items() if v is not None}
-        rules["height"], rules["width"] = feats["height"], feats["width"]
+        rules = {}
+        for k in ("ndvi", "ndwi", "mndwi", "ndbi"):
+            v = feats.get(k)
+            if v is None:
+                v = feats.get(f"all_extracted_features_dict_{k}")
+            if v is not None:
+                rules[k] = v
+        rules["height"], rules["width"] = shape
         out = rule_based_classification(rules)
-    elif key not in feats:
-        print(f"特征 '{key}' 不存在: {list(feats.keys())}")
-        return None
     elif method == "kmeans":
-        out = (unsupervised_kmeans_classification(feats, n_clusters, [key]) + 1).astype(np.uint8)
+        wanted = ["ndvi", "ndwi", "ndbi", "texture_mean", "hierarchical_all"] if feature_keys is None else list(feature_keys)
+        valid = [k for k in wanted if isinstance(feats.get(k), np.ndarray) and feats[k].ndim in (2, 3)]
+        if not valid:
+            print(f"警告: 为KMeans指定的特征键 {wanted} 在数据中均不可用，将使用自动选择。")
+        out = (unsupervised_kmeans_classification(feats, n_clusters, valid or None) + 1).astype(np.uint8)   # scripts/3:394
     elif method in ("random_forest", "rf", "supervised"):
-        if classifier is None:
-            raise ValueError("supervised classification needs a fitted classifier")
         from modules.features.extract import supervised_classification_predict
-        out = supervised_classification_predict(feats[key], classifier)
+        arr = None
+        if use_hierarchical_all:
+            for key in ("hierarchical_all", "hierarchical_features_all"):
+                v = feats.get(key)
+                if isinstance(v, np.ndarray) and v.ndim == 3 and v.shape[:2] == shape:
+                    arr = v
+                    break
+        if arr is None:   # scripts/3:425-437: every 2-D plane of the image's shape, in dict order
+            keys = [k for k, v in feats.items() if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == shape]
+            if not keys:
+                print("错误: 为随机森林指定的特征键在数据中均不可用或不是匹配图像形状的2D数组。")
+                return None
+            arr = np.stack([feats[k] for k in keys], axis=-1)
+        model_path = os.path.join(output_dir, RF_MODEL_FILE)
+        if classifier is None and os.path.exists(model_path):
+            import joblib
+            print(f"加载已训练的随机森林模型: {model_path}")
+            classifier = joblib.load(model_path)
+        if classifier is None:
+            print(f"错误: 没有可用的随机森林模型 ('{model_path}' 不存在, 未传入 classifier)；训练不在本实现范围内。")
+            return None
+        nf = getattr(classifier, "n_features_in_", None)
+        if nf is not None and nf != arr.shape[-1]:
+            print(f"警告: 加载的分类器需要 {nf} 个特征，但准备的数据有 {arr.shape[-1]} 个；重新训练不在本实现范围内。")
+            return None
+        out = supervised_classification_predict(arr, classifier)
     else:
         print(f"错误: 不支持的分割方法 '{method}'")
         return None
     np.save(os.path.join(output_dir, f"classification_{method}.npy"), out)
     if all(feats.get(k) is not None for k in ("transform", "crs", "width", "height")):
-        if out.shape == (feats["height"], feats["width"]):
+        if out.shape == shape:
             save_class_map_tif(out, os.path.join(output_dir, f"{method}_classification_map.tif"), feats["transform"], feats["crs"])
     else:
         print("警告: 元数据不完整，无法将分类结果保存为带地理参考的GeoTIFF。")
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# one-command driver shaped like the two scripts' __main__ blocks (scripts/2_feature_extraction.py:137-262,
+# scripts/3_classification.py:545-632):   python -m rsseg.stages <image.tif> <output_dir> [--classify kmeans]
+# --------------------------------------------------------------------------------------------------
+def run_scripts_2_3(image_path: str, output_dir: str, classify: Optional[str] = None, preprocessing: bool = True, n_clusters: int = 7,
+                    ctx: Optional[Context] = None) -> Dict[str, object]:
+    """Reads the GeoTIFF's bands as float32 with nodata -> NaN (scripts/2:154-161), runs the feature stage, writes
+    <output_dir>/feature_outputs/{level1,level2,all_hierarchical}_features.npy, all_features_and_metadata.pkl and
+    all_hierarchical_features.tif (scripts/2:193-258), then — `classify` in {'kmeans', 'rule_based', 'random_forest'} —
+    the classification stage on that pickle into <output_dir>/segmentation_results (scripts/3:548-551)."""
+    from .tiff import read_tiff, read_tiff_georef
+    arr = read_tiff(image_path)
+    geo = read_tiff_georef(image_path)
+    bands = []
+    for i in range(arr.shape[0]):
+        b = arr[i] if arr.dtype == np.uint8 and geo["nodata"] is None else arr[i].astype(np.float32)
+        if geo["nodata"] is not None:
+            b[b == geo["nodata"]] = np.nan
+        bands.append(b)
+    h, w = arr.shape[1:]
+    fd, hier = run_feature_extraction_stage(bands, preprocessing=preprocessing, ctx=ctx)
+    crs = None if geo["epsg"] is None else f"EPSG:{geo['epsg']}"
+    fdir = os.path.join(output_dir, "feature_outputs")
+    paths = save_feature_outputs(fdir, fd, hier, h, w, geo["transform"], crs)
+    res: Dict[str, object] = {"paths": paths, "shape": (h, w)}
+    if classify:
+        sdir = os.path.join(output_dir, "segmentation_results")
+        res["class_map"] = run_classification_stage(paths["pkl"], classify, sdir, True, n_clusters=n_clusters, ctx=ctx)
+        res["segmentation_dir"] = sdir
+    return res
+
+
+def main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m rsseg.stages",
+                                 description="feature extraction (scripts/2) and optionally classification (scripts/3) of one GeoTIFF on the GPU")
+    ap.add_argument("image")
+    ap.add_argument("output_dir")
+    ap.add_argument("--classify", choices=["kmeans", "rule_based", "random_forest"])
+    ap.add_argument("--n-clusters", type=int, default=7)
+    ap.add_argument("--no-preprocessing", action="store_true")
+    a = ap.parse_args(argv)
+    res = run_scripts_2_3(a.image, a.output_dir, a.classify, not a.no_preprocessing, a.n_clusters)
+    for k, v in res["paths"].items():
+        print(f"{k}: {v}")
+    if a.classify:
+        cm = res.get("class_map")
+        print(f"class map: {None if cm is None else (cm.shape, np.unique(cm).tolist())} -> {res['segmentation_dir']}")
+        return 0 if cm is not None else 1
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -20,6 +20,7 @@ LZW is done by the library's host helpers (rsseg_host_lzw_encode / _decode, incl
 from __future__ import annotations
 
 import ctypes as C
+import os
 import struct
 from typing import Dict, Optional, Tuple
 
@@ -225,11 +226,24 @@ def write_tiff(path: str, arr, transform=None, epsg=None, nodata=None, compress:
     isz = ledt.itemsize
     raw_total = B * H * W * isz
     if bigtiff is None:
-        bigtiff = raw_total + (1 << 20) >= 2 ** 32 - (1 << 16)
+        # LZW can GROW incompressible data (float64 noise: 9..12-bit codes for 8-bit symbols, up to ~1.4x), so with
+        # compression the choice is made on a worst-case bound; a classic file that would pass 4 GB is never started
+        worst = raw_total * 3 // 2 if lzw else raw_total
+        bigtiff = worst + (1 << 20) >= 2 ** 32 - (1 << 16)
     tx, ty = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     rows_per_strip = H if not lzw else max(1, min(H, (1 << 20) // max(W * isz, 1)))   # ~1 MB strips when compressed
     nstrips = (H + rows_per_strip - 1) // rows_per_strip
     offs, cnts = [], []
+    try:
+        _write_body(path, a, bigtiff, tiled, lzw, ledt, tx, ty, rows_per_strip, nstrips, offs, cnts, bits, fmt, transform, epsg, geographic, nodata)
+    except BaseException:
+        if os.path.exists(path):    # never leave a multi-GB partial file behind
+            os.remove(path)
+        raise
+
+
+def _write_body(path, a, bigtiff, tiled, lzw, ledt, tx, ty, rows_per_strip, nstrips, offs, cnts, bits, fmt, transform, epsg, geographic, nodata):
+    B, H, W = a.shape
     with open(path, "wb") as f:
         f.write(b"\0" * (16 if bigtiff else 8))           # header, patched at the end
         for b in range(B):
@@ -245,6 +259,8 @@ def write_tiff(path: str, arr, transform=None, epsg=None, nodata=None, compress:
                             data = lzw_encode(data)
                         offs.append(f.tell())
                         cnts.append(len(data))
+                        if not bigtiff and offs[-1] + len(data) >= 2 ** 32 - (1 << 16):
+                            raise ValueError("raster too large for classic TIFF (pass bigtiff=True)")
                         f.write(data)
                         if len(data) & 1:
                             f.write(b"\0")
@@ -255,6 +271,8 @@ def write_tiff(path: str, arr, transform=None, epsg=None, nodata=None, compress:
                         data = lzw_encode(data)
                     offs.append(f.tell())
                     cnts.append(len(data))
+                    if not bigtiff and offs[-1] + len(data) >= 2 ** 32 - (1 << 16):
+                        raise ValueError("raster too large for classic TIFF (pass bigtiff=True)")
                     f.write(data)
                     if len(data) & 1:
                         f.write(b"\0")

@@ -141,16 +141,113 @@ def test_forest_entry_points(ctx, crop, golden_dir):
         E.supervised_classification_predict(X[0], f)
 
 
-def test_classification_stage_driver(ctx, crop, tmp_path):
-    """stage 2 files -> load_features -> normalize_features_structure -> KMeans on 'hierarchical_features_all'."""
+def test_classification_stage_driver(ctx, crop, tmp_path, oracle):
+    """run_classification_stage with the reference's signature (scripts/3_classification.py:267), called the way
+    scripts/3:616-621 calls it.  On a stage-2 pickle the listed KMeans keys do not exist, so the selection is the automatic
+    one the reference announces: every 2-D plane (55), 7 clusters, labels + 1."""
+    from modules.features import extract as E
+    from rsseg import stages
+    sig = inspect.signature(stages.run_classification_stage)
+    pos = [p for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert [p.name for p in pos] == ["feature_file_path", "method", "output_dir", "use_hierarchical_all"]
+    assert [p.default for p in pos[1:]] == ["rule_based", "segmentation_outputs", True]
+    assert all(p.kind == p.KEYWORD_ONLY for n, p in sig.parameters.items() if n not in [q.name for q in pos])
+    fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
+    # features_dict and its nested members in the reference's insertion order (scripts/2:62-106, indices.py:310-316, 421-440,
+    # 463-480, 535-560): the order is the column order of the default KMeans selection
+    want_order = oracle.full_features_dict(list(crop["bands"]), pca_result=fd["pca_result"])
+    assert list(fd) == list(want_order)
+    for k in ("glcm_features", "multi_scale_features", "morphological_features", "filter_features"):
+        assert list(fd[k]) == list(want_order[k]), k
+    paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
+    out = stages.run_classification_stage(paths["pkl"], method='kmeans', output_dir=str(tmp_path / "cls"), use_hierarchical_all=True)
+    assert out.shape == (96, 96) and out.dtype == np.uint8 and out.min() == 1 and out.max() == 7
+    assert np.array_equal(np.load(tmp_path / "cls" / "classification_kmeans.npy"), out)
+    nf = E.normalize_features_structure(E.load_features(paths["pkl"]))
+    keys2d = [k for k, v in nf.items() if isinstance(v, np.ndarray) and v.ndim == 2]
+    assert len(keys2d) == 55 and keys2d == list(oracle.flatten_features_dict(want_order))
+    assert np.array_equal(out, E.unsupervised_kmeans_classification(nf, 7, None) + 1)
+    want, _ = oracle.unsupervised_kmeans_classification(nf, 7, None)          # the CPU restatement on the same 55 planes
+    assert np.array_equal(out, want + 1)
+    # explicit keys (keyword-only addition): the 19-feature stack
+    out6 = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls6"), n_clusters=6, feature_keys=["hierarchical_features_all"])
+    assert np.array_equal(out6, stages.run_kmeans_stage(hier["all"], 6))
+    # default method is 'rule_based' (scripts/3:267)
+    rb = stages.run_classification_stage(paths["pkl"], output_dir=str(tmp_path / "rb"))
+    assert rb.dtype == np.uint8 and (tmp_path / "rb" / "classification_rule_based.npy").exists()
+
+
+def test_classification_stage_forest_branch_loads_the_joblib_model(ctx, crop, tmp_path):
+    """scripts/3:401-488, inference part: <output_dir>/random_forest_model.joblib is loaded when its n_features_in_ matches
+    (:459-475); `use_hierarchical_all` picks the 19-feature stack, False stacks every 2-D plane (55, :425-437)."""
+    import joblib
+    from sklearn.ensemble import RandomForestClassifier
+    from modules.features import extract as E
     from rsseg import stages
     fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
-    out = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls"), n_clusters=6)
-    assert out.shape == (96, 96) and out.dtype == np.uint8 and out.min() == 1 and out.max() == 6
-    assert np.array_equal(np.load(tmp_path / "cls" / "classification_kmeans.npy"), out)
-    direct = stages.run_kmeans_stage(hier["all"], 6)
-    assert np.array_equal(out, direct)
+    rng = np.random.default_rng(5)
+    idx = rng.choice(96 * 96, 600, replace=False)
+    y = (fd["ndvi"].reshape(-1)[idx] > np.median(fd["ndvi"])).astype(np.int64) + 2 * (fd["ndwi"].reshape(-1)[idx] > 0) + 1
+    X19 = hier["all"].reshape(-1, 19)
+    m19 = RandomForestClassifier(n_estimators=20, random_state=0).fit(X19[idx], y)
+    out_dir = tmp_path / "rf19"
+    out_dir.mkdir()
+    assert stages.run_classification_stage(paths["pkl"], "random_forest", str(out_dir)) is None     # no model yet: reported, None
+    joblib.dump(m19, out_dir / stages.RF_MODEL_FILE)
+    got = stages.run_classification_stage(paths["pkl"], "random_forest", str(out_dir), True)
+    assert got.dtype == np.int64 and np.array_equal(got, m19.predict(X19).reshape(96, 96))
+    # every 2-D plane: 55 features
+    nf = E.normalize_features_structure(E.load_features(paths["pkl"]))
+    X55 = np.stack([v for v in nf.values() if isinstance(v, np.ndarray) and v.ndim == 2], -1).reshape(-1, 55)
+    m55 = RandomForestClassifier(n_estimators=20, random_state=1).fit(X55[idx], y)
+    out55 = tmp_path / "rf55"
+    out55.mkdir()
+    joblib.dump(m55, out55 / stages.RF_MODEL_FILE)
+    got55 = stages.run_classification_stage(paths["pkl"], "random_forest", str(out55), False)
+    assert np.array_equal(got55, m55.predict(X55).reshape(96, 96))
+    assert stages.run_classification_stage(paths["pkl"], "random_forest", str(out_dir), False) is None   # 19-feature model, 55 planes
+    assert np.array_equal(stages.run_classification_stage(paths["pkl"], "random_forest", str(tmp_path / "kw"), classifier=m19), got)
+
+
+def test_kmeans_default_key_selection_equals_the_reference_on_55_planes(ctx, golden_dir, oracle):
+    """The DEFAULT call of unsupervised_kmeans_classification (feature_keys_to_use=None, extract.py:516-522): every 2-D
+    plane of a stage-2-shaped dictionary, 55 float32 / float64 planes -> a float64 matrix.  The labels were produced by the
+    reference function itself (oracle/gen_golden.py, tests/golden/crop96_stage2.npz)."""
+    from modules.features import extract as E
+    g = np.load(os.path.join(golden_dir, "crop96_stage2.npz"))
+    d = {str(k): g[f"plane_{i:02d}"] for i, k in enumerate(g["keys"])}
+    assert len(d) == 55 and {v.dtype for v in d.values()} == {np.dtype(np.float32), np.dtype(np.float64)}
+    d["height"], d["width"] = int(g["height"]), int(g["width"])
+    d["transform"], d["crs"] = None, None
+    for k in (5, 8):
+        got = E.unsupervised_kmeans_classification(d, k) if k == 5 else E.unsupervised_kmeans_classification(d, k, None)
+        assert got.dtype == np.int32 and np.array_equal(got, g[f"kmeans_auto_k{k}"]), k
+    planes = [ctx.to_device(np.ascontiguousarray(v, np.float64).reshape(-1)) for v in list(d.values())[:55]]
+    labels, meta = ctx.kmeans_fit_predict(planes, 8)
+    want, info = oracle.kmeans_fit_planes([np.asarray(v, np.float64) for v in list(d.values())[:55]], 8)
+    assert meta["n_iter"] == info["n_iter"] and np.array_equal(meta["init_indices"], info["init_indices"])
+    assert np.array_equal(labels.cpu().numpy(), want)
+
+
+def test_scripts_2_3_driver_on_the_bundled_scene(ctx, golden_dir, tmp_path):
+    """python -m rsseg.stages <image.tif> <outdir> --classify kmeans: BASELINE configs[0] as one command — GeoTIFF in,
+    the files of scripts/2:193-258 and scripts/3:491-498 out."""
+    from rsseg import stages
+    from rsseg.tiff import read_tiff, write_tiff
+    dn = np.load(os.path.join(golden_dir, "scene_aa.npz"))["dn"][:, 100:356, 200:456]
+    tr = (30.0, 0.0, 440000.0, 0.0, -30.0, 3300000.0)
+    write_tiff(str(tmp_path / "in.tif"), dn, transform=tr, epsg=32649)
+    assert stages.main([str(tmp_path / "in.tif"), str(tmp_path / "out"), "--classify", "kmeans", "--n-clusters", "6"]) == 0
+    fo = tmp_path / "out" / "feature_outputs"
+    for name in ("level1_features.npy", "level2_features.npy", "all_hierarchical_features.npy", "all_features_and_metadata.pkl",
+                 "all_hierarchical_features.tif"):
+        assert (fo / name).exists(), name
+    allf = np.load(fo / "all_hierarchical_features.npy")
+    assert allf.shape == (256, 256, 19) and allf.dtype == np.float64
+    cm = read_tiff(str(tmp_path / "out" / "segmentation_results" / "kmeans_classification_map.tif"))[0]
+    assert cm.dtype == np.uint8 and cm.shape == (256, 256) and cm.min() == 1 and cm.max() == 6
+    assert np.array_equal(cm, np.load(tmp_path / "out" / "segmentation_results" / "classification_kmeans.npy"))
 
 
 def _pca_f64(bands, scaled_fn):
@@ -234,7 +331,7 @@ def test_classification_stage_writes_the_geotiff(ctx, crop, tmp_path):
     tr = (30.0, 0.0, 440000.0, 0.0, -30.0, 3300000.0)
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96, transform=tr, crs="EPSG:32649")
     assert np.array_equal(np.moveaxis(read_tiff(paths["tif"]), 0, -1), hier["all"])       # LZW tiles, float64, 19 bands
-    out = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls"), n_clusters=5)
+    out = stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "cls"), n_clusters=5, feature_keys=["hierarchical_features_all"])
     tif = tmp_path / "cls" / "kmeans_classification_map.tif"
     assert tif.exists()
     back = read_tiff(str(tif))
@@ -303,6 +400,19 @@ def test_rule_based_classification_vs_oracle(ctx, scene, oracle, tmp_path):
     assert set(np.unique(want)) >= {0, 1} and (want > 0).mean() > 0.2        # a non-trivial map
     no_mndwi = {k: v for k, v in feats.items() if k != "mndwi"}
     assert np.array_equal(E.rule_based_classification(no_mndwi), oracle.rule_based_classification(no_mndwi))
+    # NaN pixels: threshold_segmentation counts them as 0 (extract.py:354-356), the bare-land band tests do not
+    # (extract.py:486-497: a NaN fails both comparisons, although 0 lies inside (-0.1, 0.2) and (-0.2, 0.2))
+    holes = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in feats.items()}
+    for key in ("ndvi", "ndbi", "mndwi"):
+        holes[key][300:340, 100:180] = np.nan
+    holes["ndvi"][::37, ::11] = np.nan
+    want_h = oracle.rule_based_classification(holes)
+    assert np.array_equal(E.rule_based_classification(holes), want_h)
+    assert not (want_h[300:340, 100:180] == 4).any()
+    zeros = {k: (np.nan_to_num(v, nan=0.0) if isinstance(v, np.ndarray) else v) for k, v in holes.items()}
+    assert (oracle.rule_based_classification(zeros)[300:340, 100:180] == 4).any()      # with 0 instead of NaN the block IS bare land
+    bl = E.extract_bareland_by_rule(holes, None, None, None)
+    assert not bl[300:340, 100:180].any()
     for fn in ("extract_vegetation_by_threshold", "extract_water_by_threshold", "extract_builtup_by_threshold"):
         m = getattr(E, fn)(feats)
         assert m.shape == (600, 600) and m.dtype == np.uint8

@@ -500,8 +500,9 @@ def test_kmeans_errors(ctx):
     x = dev(ctx, np.zeros(3, np.float32))
     with pytest.raises(ValueError):
         ctx.kmeans_fit_predict([x], 5)  # n_samples < n_clusters
-    with pytest.raises(ValueError):
-        ctx.kmeans_fit_predict([x] * 40, 2)  # too many features
+    from rsseg.runtime import RssegUnsupported
+    with pytest.raises(RssegUnsupported):
+        ctx.kmeans_fit_predict([dev(ctx, np.zeros(300, np.float32))] * 65, 2)  # more planes than RSSEG_MAX_FEATURES (64)
 
 
 def test_producer_minmax_tags_and_kmeans_shortcut(ctx, crop, oracle):
@@ -633,10 +634,12 @@ def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
     assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("F", [1, 2, 8, 32])
+@pytest.mark.parametrize("F", [1, 2, 8, 32, 33, 55, 64])
 def test_forest_feature_counts_vs_sklearn(ctx, oracle, F):
-    """Feature counts 1, even, and the maximum (32): a pixel's features are one LDS row of F | 1 floats and a node's
-    byte 3 is 4 x feature; NaN rows included; a pixel count that leaves the last workgroup ragged."""
+    """Feature counts 1, even, 32 (the last count with 1024 pixels per workgroup) and 33 / 55 / 64 (512 pixels per
+    workgroup; 55 = every 2-D plane of the stage-2 dictionary, the reference's non-hierarchical forest branch,
+    scripts/3_classification.py:425-437): a pixel's features are one LDS row of F | 1 floats and a node's byte 3 is
+    4 x feature; NaN rows included; a pixel count that leaves the last workgroup ragged."""
     from sklearn.ensemble import RandomForestClassifier
     rng = np.random.default_rng(100 + F)
     Xtr = rng.random((4000, F)).astype(np.float32)
@@ -670,7 +673,7 @@ def test_forest_large_trees_many_classes_and_infinities_vs_sklearn(ctx, oracle):
     fin = np.isfinite(Xs) | np.isnan(Xs)
     Xs[~fin] = np.sign(Xs[~fin]) * 3.0e38                    # sklearn refuses inf input; the same comparisons with huge values
     assert np.array_equal(got, big.predict(Xs))
-    for ncls in (11, 20):
+    for ncls in (11, 20, 40, 64):                              # 33 .. 64 classes: 512 pixels per workgroup, 64-wide vote rows
         Xt = rng.random((8000, 5)).astype(np.float32)
         yt = ((Xt[:, 1] * ncls).astype(np.int64) + (rng.random(8000) < 0.15) * rng.integers(0, ncls, 8000)) % ncls * 3 + 100  # labels 100, 103, ...
         m = RandomForestClassifier(n_estimators=15, max_depth=10, random_state=2, n_jobs=4).fit(Xt, yt)
@@ -678,6 +681,13 @@ def test_forest_large_trees_many_classes_and_infinities_vs_sklearn(ctx, oracle):
         Xp = rng.random((3001, 5)).astype(np.float32)
         ctx.forest_load(oracle.flatten_forest(m))
         assert np.array_equal(host(ctx.forest_predict([dev(ctx, Xp[:, i]) for i in range(5)])), m.predict(Xp)), ncls
+    # beyond the capacity of the kernels the library refuses loudly (no all-zero map): 65 classes
+    f65 = dict(oracle.flatten_forest(m))
+    f65["value"] = np.concatenate([f65["value"], np.zeros((f65["value"].shape[0], 65 - f65["value"].shape[1]))], 1)
+    f65["classes"] = np.arange(65)
+    from rsseg.runtime import RssegUnsupported
+    with pytest.raises(RssegUnsupported):
+        ctx.forest_load(f65)
 
 
 def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
@@ -759,10 +769,12 @@ def test_kmeans_empty_cluster_relocation(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("k,F,dt", [(12, 5, np.float32), (20, 20, np.float32), (40, 3, np.float32), (33, 9, np.float64), (2, 1, np.float32),
-                                    (1, 4, np.float32), (16, 32, np.float32)])
+                                    (1, 4, np.float32), (16, 32, np.float32),
+                                    (5, 33, np.float32), (8, 55, np.float64), (12, 64, np.float32), (20, 40, np.float64), (40, 48, np.float32)])
 def test_kmeans_many_clusters_and_features(ctx, oracle, k, F, dt):
-    """Every kernel instantiation (KMAX 8/16/32/64 x 8/16/32 register-resident features, float32 and float64)
-    against the oracle, on clumpy data so that the iteration count is non-trivial."""
+    """Every kernel instantiation (KMAX 8/16/32/64 x 8/16/32 register-resident features, and the feature-blocked
+    kernels for 33..64 features; float32 and float64) against the oracle, on clumpy data so that the iteration count is
+    non-trivial."""
     rng = np.random.default_rng(k * 100 + F)
     n = 20011
     cent = rng.random((k + 3, F))

@@ -238,3 +238,73 @@ def test_stripe_rows_cover_the_raster_and_refuse_empty_stripes():
         P.stripe_rows(7, 8, 0)
     with pytest.raises(ValueError):
         P.stripe_rows(100, 4, 4)
+
+
+def test_run_classification_stage_has_the_reference_signature():
+    """scripts/3_classification.py:267: (feature_file_path, method='rule_based', output_dir="segmentation_outputs",
+    use_hierarchical_all=True); everything else this implementation adds is keyword-only."""
+    import inspect
+    from rsseg import stages
+    sig = inspect.signature(stages.run_classification_stage)
+    pos = [p for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert [(p.name, p.default) for p in pos] == [("feature_file_path", inspect.Parameter.empty), ("method", "rule_based"),
+                                                  ("output_dir", "segmentation_outputs"), ("use_hierarchical_all", True)]
+    assert {n for n, p in sig.parameters.items() if p.kind == p.KEYWORD_ONLY} == {"n_clusters", "classifier", "feature_keys", "ctx"}
+    assert sig.parameters["n_clusters"].default == 7          # scripts/3:390
+    sig2 = inspect.signature(stages.run_feature_extraction_stage)
+    assert list(sig2.parameters)[:3] == ["bands_data", "preprocessing", "texture_band_index"]
+
+
+def test_classification_stage_error_paths_need_no_gpu(tmp_path, capsys):
+    """The reference prints and returns on unusable input (scripts/3:283-311, 489-490); FileNotFoundError is caught there too."""
+    from rsseg import stages
+    assert stages.run_classification_stage(str(tmp_path / "missing.pkl"), "kmeans", str(tmp_path / "o")) is None
+    import pickle
+    with open(tmp_path / "empty.pkl", "wb") as f:
+        pickle.dump({"dimensions": (4, 4)}, f)
+    assert stages.run_classification_stage(str(tmp_path / "empty.pkl"), "kmeans", str(tmp_path / "o")) is None
+    with open(tmp_path / "ok.pkl", "wb") as f:
+        pickle.dump({"all_extracted_features_dict": {"ndvi": np.zeros((4, 4), np.float32)}, "dimensions": (4, 4)}, f)
+    assert stages.run_classification_stage(str(tmp_path / "ok.pkl"), "no_such_method", str(tmp_path / "o")) is None
+    assert "不支持的分割方法" in capsys.readouterr().out
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([_sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 3` run bare — the form of the driver's command — starts 3 fresh ranks with the rendezvous
+    environment, waits for them and relays rank 0's single JSON line (here: the CPU self-test of the launch, a gloo
+    all-reduce of rank + 1 over 3 ranks = 6)."""
+    import json
+    r = _bench("--gpus", "3", "--launch-selftest")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["sum_of_rank_ids_plus_1"] == 6.0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench("--gpus", "2", "--launch-selftest", env={"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    r = _bench("--gpus", "1", "--launch-selftest", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0
+    r = _bench("--gpus", "1", "--launch-selftest")           # one rank, no rendezvous
+    assert r.returncode == 0 and '"n_gpus": 1' in r.stdout
+
+
+def test_bench_reports_a_failed_rank():
+    """A rank that dies (here: no GPU in the CPU container, every rank of the real bench exits) makes the launcher exit
+    non-zero instead of printing a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a host without a GPU")
+    r = _bench("--gpus", "2", "--steps", "1", "--no-cpu-baseline")
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

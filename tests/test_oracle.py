@@ -71,6 +71,33 @@ def test_kmeans_stack19_f64_labels_equal_sklearn(oracle, crop, k):
     assert np.array_equal(labels, crop[f"kmeans_stack19_k{k}"].reshape(-1))
 
 
+def test_kmeans_default_selection_55_planes_equals_reference(oracle, golden_dir):
+    """The reference's DEFAULT call (feature_keys_to_use=None -> every 2-D plane of a stage-2-shaped dictionary, 55 mixed
+    float32 / float64 planes, extract.py:516-522, 568): the restatement reproduces the labels the reference function
+    returned (tests/golden/crop96_stage2.npz, written by oracle/gen_golden.py), 0 mismatches for k = 5 (the default) and 8."""
+    g = np.load(os.path.join(golden_dir, "crop96_stage2.npz"))
+    d = {str(k): g[f"plane_{i:02d}"] for i, k in enumerate(g["keys"])}
+    d["height"], d["width"] = int(g["height"]), int(g["width"])
+    assert len(oracle.select_feature_planes(d, None)) == 55
+    for k in (5, 8):
+        lab, info = oracle.unsupervised_kmeans_classification(d, k, None)
+        assert np.array_equal(lab, g[f"kmeans_auto_k{k}"]), k
+
+
+def test_full_features_dict_key_order_is_the_reference_key_rule(oracle, golden_dir):
+    """flatten_features_dict(full_features_dict(...)) names the 55 planes as the reference's normalize_features_structure
+    named them when the fixture was written."""
+    g = np.load(os.path.join(golden_dir, "crop96_stage2.npz"))
+    keys = [str(k) for k in g["keys"]]
+    assert keys[:9] == [f"all_extracted_features_dict_{n}" for n in ("ndvi", "evi", "msavi", "ndwi", "mndwi", "ndbi", "bsi", "pca_result_0", "pca_result_1")]
+    assert keys[19] == "all_extracted_features_dict_lbp_feature" and keys[20] == "all_extracted_features_dict_multi_scale_features_mean_scale_1"
+    assert keys[-1] == "all_extracted_features_dict_filter_features_sobel_mag"
+    z = np.zeros((4, 5), np.float32)
+    fd = {"ndvi": z, "pca_result": [z, z], "variance_ratio": np.zeros(2), "glcm_features": {"Contrast": z}}
+    assert list(oracle.flatten_features_dict(fd)) == ["all_extracted_features_dict_ndvi", "all_extracted_features_dict_pca_result_0",
+                                                      "all_extracted_features_dict_pca_result_1", "all_extracted_features_dict_glcm_features_contrast"]
+
+
 def test_kmeans_nan_replaced_by_zero(oracle, crop):
     planes = [crop["idx_" + n] for n in KEYS]
     planes[0] = crop["kmeans_idx7_nan_input"]
