@@ -35,14 +35,33 @@ import numpy as np  # noqa: E402
 SYNTH_STRIPE = 2048
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
+N_CU = 256
+# The forest walk is bound by dependent LDS gathers: a node visit is two of them (the pixel's feature, then the child
+# node).  profiles/ubench/ubench.hip -> profiles/r02_ubench.json, "lds_dependent_chain", 16 waves per CU, 4 chains per wave:
+# 545.5 ticks per round of 16 waves x 4 chains x 2 gathers = 4.26 cycles per wave-instruction per CU.
+LDS_GATHER_CYCLES = 4.26
+FOREST_VISITS_PEAK = N_CU * CLOCK_HZ / LDS_GATHER_CYCLES * 64 / 2
 
 
-def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
+HARD_NOTE = ("the same eight prototypes mixed continuously (abundances following six plane waves of 350..5000-px period, noise N(0, 9)): "
+             "smooth gradients and overlapping classes, so that KMeans needs tens of Lloyd iterations like the bundled real scene (47-51)")
+HARD = dict(waves=((1 / 2311.0, 1 / 3119.0, 0.3), (1 / 1277.0, -1 / 1913.0, 1.7), (-1 / 811.0, 1 / 1499.0, 2.9), (1 / 523.0, 1 / 677.0, 4.1),
+                   (1 / 5003.0, -1 / 4001.0, 5.3), (-1 / 347.0, -1 / 433.0, 0.9)),
+            noise=9.0, sharp=1.6)
+
+
+def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7, kind="easy"):
     """SURVEY.md §8(d) generator, evaluated on the device: 8 spectral prototypes on a 64-px checkerboard
     + N(0, 6) noise, clipped, truncated to uint8, stored as float32 (integer-valued DN like the real
     preprocessed tile).  Returns the planes `want` for GLOBAL rows [g0, g1); every 2048-row stripe of the scene
     has its own seed and is always generated whole, so any rank reproduces any row of the scene exactly
-    (needed for the halos of a row-sharded raster)."""
+    (needed for the halos of a row-sharded raster).  The noise comes from torch's device generator (Philox, seeded per
+    stripe): the same rows on any rank of one run and on any MI355X with this torch build; a different torch / rocRAND
+    build may draw different noise — the bench compares ranks and kernels within one run, the parity tests use
+    oracle.synthetic_raster (NumPy default_rng, as §8(d) writes it).
+    kind="hard": the same prototypes MIXED continuously — abundances that follow six plane waves of 350..5000-px period
+    across the scene, noise N(0, 9) — i.e. smooth gradients and overlapping classes instead of eight separable ones:
+    KMeans then needs tens of Lloyd iterations, like the bundled real scene (47-51), not 6."""
     proto = torch.tensor(np.random.default_rng(355).integers(20, 230, (8, bands)), dtype=torch.float32, device=device)
     want = list(want)
     out = {b: torch.empty((g1 - g0) * W, dtype=torch.float32, device=device) for b in want}
@@ -52,12 +71,24 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7):
         g = torch.Generator(device=device)
         g.manual_seed(355_000 + s)
         y = (torch.arange(SYNTH_STRIPE, device=device) + s0)[:, None]
-        lab = ((y // 64) * 7 + (x // 64) * 3) % 8
         a, b_ = max(g0, s0), min(g1, s0 + SYNTH_STRIPE)
+        if kind == "hard":
+            xf, yf = x.to(torch.float32), y.to(torch.float32)
+            # eight abundance fields from six plane waves; softmax-like mixing keeps every DN inside the prototypes' hull
+            ph = [torch.cos(6.2831855 * (fx * xf + fy * yf) + p0) for fx, fy, p0 in HARD["waves"]]
+            mix = torch.tensor(np.random.default_rng(77).normal(0, 1.0, (8, len(ph))), dtype=torch.float32, device=device)
+            wts = torch.stack([sum(mix[i, j] * ph[j] for j in range(len(ph))) for i in range(8)])
+            wts = torch.softmax(HARD["sharp"] * wts, dim=0)
+            del ph
+        else:
+            lab = ((y // 64) * 7 + (x // 64) * 3) % 8
         for b in range(bands):
             noise = torch.randn(SYNTH_STRIPE, W, generator=g, device=device)  # always drawn: keeps the stream aligned
             if b in out:
-                v = (proto[lab, b] + noise * 6.0)[a - s0:b_ - s0]
+                if kind == "hard":
+                    v = ((wts * proto[:, b][:, None, None]).sum(0) + noise * HARD["noise"])[a - s0:b_ - s0]
+                else:
+                    v = (proto[lab, b] + noise * 6.0)[a - s0:b_ - s0]
                 out[b][(a - g0) * W:(b_ - g0) * W] = v.clamp_(0, 255).to(torch.uint8).to(torch.float32).reshape(-1)
     return [out[b] for b in want]
 
@@ -70,6 +101,8 @@ def family_table(cfg, F, glcm_step, k, n_pca):
     return {
         "kpp": ("hbm", (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1)),   # k passes: F planes in, closest plane r/w from round 2 on
         "lloyd": ("hbm", 4 * F + 2),
+        "moment": ("hbm", 4 * F),                                          # column means of the scaled matrix: F planes in
+        "labels": ("hbm", 5),                                              # uint8 labels in, int32 labels out
         "select": ("hbm", 4),                                              # one radix pass over one float32 plane
         "indices": ("hbm", 20 + idx_out),
         "normalize": ("hbm", 8), "quantize": ("hbm", 5),
@@ -77,9 +110,16 @@ def family_table(cfg, F, glcm_step, k, n_pca):
         "resize": ("hbm", 8),                                              # 4 taps from cache, one plane out
         "box": ("hbm", 8), "ctxmean": ("hbm", 8 * 7), "morph": ("hbm", 2), "filt_max": ("hbm", 1), "filt_write": ("hbm", 5),
         "glcm": ("valu", 4 + 20.0 / (glcm_step * glcm_step)),
-        "forest": ("latency", 4 * F + 8),
+        "forest": ("lds_gather", 4 * F + 8),
     }
 
+
+# MFMA: the only dense contraction of the path is the 7x7 Gram / 7x3 projection of the PCA (3.5 flop/B).  It runs on the vector
+# ALUs with exact fixed-point accumulation; no MFMA instruction is issued by any kernel of the step (rocprofv3 --pmc
+# SQ_INSTS_VALU_MFMA_* = 0 for every kernel: profiles/r03_c3_pmc_sq.md), so the utilisation north_star asks to report is 0.
+MFMA_UTIL = {"value": 0.0, "note": "no MFMA instruction in the step (SQ_INSTS_MFMA = 0 for every kernel, profiles/r03_c3_pmc_sq.md); "
+                                   "the PCA Gram / projection (2 x 7 x 7 flop per 28 B) run on the VALU with exact fixed-point sums — "
+                                   "see DESIGN.md 5 for the MFMA Gram that was measured against it"}
 
 # dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
 PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_pair",
@@ -113,7 +153,7 @@ def pattern_rate_gbs(family):
     one read-modify-write plane for the k-means kernels (profiles/r02_streams.json, best of the recorded runs) — or None."""
     try:
         runs = json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]
-        key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("with_rw_plane", "15"), "moment": ("read_only", "15")}[family]
+        key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("with_rw_plane", "15"), "moment": ("read_only", "1")}[family]
         return round(max(r[key][ns] for r in runs if key in r) * 1000.0, 1)
     except Exception:  # noqa: BLE001
         return None
@@ -220,6 +260,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
     ap.add_argument("--size", type=int, default=0, help="raster edge (default 16384 for c3 / c5, 4096 for c2)")
     ap.add_argument("--glcm-step", type=int, default=1)
+    ap.add_argument("--data", default="easy", choices=["easy", "hard"],
+                    help="synthetic raster: 'easy' = SURVEY 8d's eight separable prototypes (KMeans converges in ~6 iterations), "
+                         "'hard' = continuously mixed prototypes (tens of iterations, like the bundled real scene)")
     ap.add_argument("--cpu-crop", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and GLCM-step-7 side measurements")
@@ -279,13 +322,13 @@ def main():
     nir_ext, i0, e0 = None, r0, r0
     if cfg == "c5" and world > 1:
         e0, e1 = P.stack19_halo_rows(Hg, r0, r1)
-        bands = synth_rows(torch, device, W, e0, e1)                      # rows [e0, e1) of every band
+        bands = synth_rows(torch, device, W, e0, e1, kind=args.data)      # rows [e0, e1) of every band
     else:
-        bands = synth_rows(torch, device, W, r0, r1)
+        bands = synth_rows(torch, device, W, r0, r1, kind=args.data)
         if cfg == "c3" and world > 1:
             _, _, i0, i1 = P.glcm_halo_rows(Hg, r0, r1, 7, args.glcm_step)
-            top = synth_rows(torch, device, W, i0, r0, want=[3])[0] if i0 < r0 else bands[3][:0]
-            bot = synth_rows(torch, device, W, r1, i1, want=[3])[0] if i1 > r1 else bands[3][:0]
+            top = synth_rows(torch, device, W, i0, r0, want=[3], kind=args.data)[0] if i0 < r0 else bands[3][:0]
+            bot = synth_rows(torch, device, W, r1, i1, want=[3], kind=args.data)[0] if i1 > r1 else bands[3][:0]
             nir_ext = torch.cat([top, bands[3], bot])
     torch.cuda.synchronize()
 
@@ -294,7 +337,7 @@ def main():
         forest_model = fit_c5_forest(torch, dist, device, P, rank, world, W)
         ctx.forest_load(forest_model["flat"])
 
-    def step(glcm_step=args.glcm_step):
+    def step(glcm_step=args.glcm_step, bands=bands):
         if cfg == "c3" and world > 1:
             labels, meta, _ = P.config3_striped(ctx, bands, nir_ext, Hg, W, r0, r1, i0, k, 7, glcm_step, 3)
             return labels, meta
@@ -350,22 +393,46 @@ def main():
     comm_ms, comm_cnt = ctx.prof_get("allreduce")
     ctx.prof_enable(False)
 
-    # ---- side measurements (rank 0, N = 1): the GLCM step-7 variant and the PCIe-inclusive rate ----
+    # ---- side measurements (rank 0, N = 1): GLCM step 7, the other synthetic raster, north_star's literal configuration,
+    # and the PCIe-inclusive rates — never the bench `value` ----
     extras = {}
+
+    def timed(fn, reps=2):
+        nonlocal labels
+        labels = None
+        fn()                                   # warm
+        torch.cuda.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ts = time.perf_counter()
+        m = None
+        for _ in range(reps):
+            labels = None
+            labels, m = fn()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - ts) / reps
+        lms, lcnt = ctx.prof_get("lloyd")
+        kms, _ = ctx.prof_get("kpp")
+        ctx.prof_enable(False)
+        out = {"ms_per_step": round(t * 1e3, 2), "value": round(n_global / 1e6 / t, 2)}
+        if m:
+            out.update({"kmeans_n_iter": int(m["n_iter"]), "ms_per_lloyd_iter": round(lms / max(lcnt, 1), 3), "ms_kpp": round(kms / reps, 2),
+                        "ms_lloyd": round(lms / reps, 2)})
+        return out
+
     if world == 1 and not args.no_extras:
         if cfg == "c3" and args.glcm_step == 1:
-            labels = None
-            step(7)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(2):
-                labels = None
-                labels, _m = step(7)
-            torch.cuda.synchronize()
-            t7 = (time.perf_counter() - ts) / 2
-            extras["glcm_step7"] = {"ms_per_step": round(t7 * 1e3, 2), "value": round(n_global / 1e6 / t7, 2),
-                                    "note": "same path with step_size=7 (the reference's non-overlapping windows, SURVEY.md 8d)"}
-        extras["pcie_inclusive"] = pcie_inclusive(torch, device, bands, step, n_global)
+            extras["glcm_step7"] = dict(timed(lambda: step(7)), note="same path with step_size=7 (the reference's non-overlapping windows, SURVEY.md 8d)")
+        if cfg in ("c2", "c3"):
+            other = "hard" if args.data == "easy" else "easy"
+            ob = synth_rows(torch, device, W, r0, r1, kind=other)
+            extras[f"{other}_raster"] = dict(timed(lambda: step(bands=ob), reps=2),
+                                             note=HARD_NOTE if other == "hard" else "SURVEY.md 8d raster: eight separable prototypes on a 64-px checkerboard")
+            del ob
+        if cfg == "c3" and H == 16384:
+            extras["north_star_c2_16384"] = dict(timed(lambda: run_c2(ctx, P, bands, 6, n_global)),
+                                                 note="BASELINE.json north_star's literal target configuration: 7 spectral indices + KMeans(k=6) on the 16384x16384x7 raster, 1 GPU (target: >= 100 Mpixel/s)")
+        extras["pcie_inclusive"] = pcie_inclusive(torch, device, ctx, bands, step, n_global)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -400,21 +467,34 @@ def main():
                 ent["valu_insts_per_wave"] = insts
                 ent["windows_per_wave"] = win_per_wave
                 ent["kernel"] = kern
-            elif bound == "latency" and visits:
+            elif bound == "lds_gather" and visits:
                 ent["node_visits_per_px"] = round(visits, 1)
                 ent["node_visits_per_s"] = round(px * visits / per_launch_s, 0)
-                ent["frac"] = None
+                ent["peak_node_visits_per_s"] = round(FOREST_VISITS_PEAK, 0)
+                ent["frac"] = round(ent["node_visits_per_s"] / FOREST_VISITS_PEAK, 4)
+                ent["bound_note"] = (f"a node visit = 2 dependent LDS gathers; {LDS_GATHER_CYCLES} cycles per gather wave-instruction per CU "
+                                     "(profiles/r02_ubench.json) x 256 CUs x 2.4 GHz x 64 lanes / 2")
             kernels.append(ent)
         roof = None
         if kernels:
-            dom = kernels[0]                      # the family with the most time per step
-            hbm = [e for e in kernels if e["bound"] == "hbm"]
-            lead = dom if dom["bound"] == "hbm" or not hbm else hbm[0]
+            dom = kernels[0]                      # the family with the most time per step LEADS the roofline object
             px = n_own
-            roof = {"bound": lead["bound"], "kernel": lead["name"], "achieved": lead["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": lead["hbm_frac"], "traffic": pmc_traffic_bytes(lead["name"], px) if (H == 16384 and world == 1) else None,
-                    "algorithmic_bytes": round(px * lead["algorithmic_B_per_px"]), "avg_launch_ms": lead["avg_ms"],
-                    "dominant_by_time": dom["name"], "kernels": kernels}
+            if dom["bound"] == "lds_gather" and dom.get("frac") is not None:
+                roof = {"bound": "lds_gather", "kernel": dom["name"], "achieved": dom["node_visits_per_s"], "peak": dom["peak_node_visits_per_s"],
+                        "unit": "node visits/s", "frac": dom["frac"], "traffic": pmc_traffic_bytes(dom["name"], px) if (H == 16384 and world == 1) else None,
+                        "algorithmic_bytes": round(px * dom["algorithmic_B_per_px"]), "hbm_frac": dom["hbm_frac"], "avg_launch_ms": dom["avg_ms"]}
+            else:
+                hbm = [e for e in kernels if e["bound"] == "hbm"]
+                lead = dom if dom["bound"] == "hbm" or not hbm else hbm[0]
+                roof = {"bound": lead["bound"], "kernel": lead["name"], "achieved": lead["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": lead["hbm_frac"], "traffic": pmc_traffic_bytes(lead["name"], px) if (H == 16384 and world == 1) else None,
+                        "algorithmic_bytes": round(px * lead["algorithmic_B_per_px"]), "avg_launch_ms": lead["avg_ms"]}
+            roof["dominant_by_time"] = dom["name"]
+            # north_star: "MFMA used only for the PCA covariance/projection GEMM, with rocprof-reported ... MFMA utilisation"
+            roof["mfma_util"] = MFMA_UTIL["value"]
+            roof["mfma_note"] = MFMA_UTIL["note"]
+            roof["kernels"] = kernels
+            roof["kernels_ms_per_step"] = round(sum(e["ms_per_step"] for e in kernels), 2)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(bands, H, W, min(args.cpu_crop, 1024) if cfg == "c5" else args.cpu_crop, cfg, k, args.glcm_step,
@@ -424,14 +504,17 @@ def main():
             "metric": "Mpixel/s feature-extract+classify", "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (scene + ", robust-normalise + 7 spectral indices"
+            "config": {"workload": (scene + (" (continuously mixed prototypes: --data hard)" if args.data == "hard" else "") + ", robust-normalise + 7 spectral indices"
                                     + (f" + GLCM(7x7, step {args.glcm_step}, 32 levels, 4 angles) + RobustScaler/PCA(3)" if cfg == "c3" else "")
                                     + (f" -> {F} float32 features -> MinMax + KMeans(k={k}, k-means++, random_state=42)" if cfg != "c5" else
                                        " + PCA + GLCM(21/21) + 7x7 context + morphology/std/Sobel -> 19-feature stack -> RandomForest(100 trees, max_depth 16) inference")),
                        "baseline_config": {"c2": "configs[1]", "c3": "configs[2]" if world == 1 else "configs[3]", "c5": "configs[4]"}[cfg],
                        "raster": [Hg, W, 7], "rows_per_rank": r1 - r0, "n_features": F, "n_clusters": k if cfg != "c5" else None,
                        "kmeans_n_iter": int(meta["n_iter"]) if meta else None,
-                       "parallelism": (f"one raster row-striped x{world}, RCCL all-reduce of histograms / PCA sums / KMeans partials / Sobel max"
+                       "ms_per_lloyd_iter": round(fams["lloyd"][0] / fams["lloyd"][1], 3) if "lloyd" in fams else None,
+                       "ms_kpp_per_step": round(fams["kpp"][0] / args.steps, 2) if "kpp" in fams else None,
+                       "data_kind": args.data,
+                       "parallelism": (f"one raster row-striped x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of histograms / PCA sums / KMeans partials / Sobel max"
                                        if world > 1 else "single GPU"),
                        "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3),
                        **extras},
@@ -506,9 +589,12 @@ def forest_visits_per_px(torch, P, ctx, bands, H, W, n_global, model, sample=655
         return None
 
 
-def pcie_inclusive(torch, device, bands, step, n_global):
-    """One step with the 7 bands coming from pinned host memory and the labels going back to it (transfers not overlapped
-    with compute): the second figure SURVEY.md §8d asks for.  Never the bench `value`."""
+def pcie_inclusive(torch, device, ctx, bands, step, n_global):
+    """The second figure SURVEY.md §8d asks for, each as ONE measured pass (wall clock around upload -> step -> download,
+    transfers not overlapped with compute): (a) the 7 bands as float32 from pinned host memory, int32 / int64 labels back;
+    (b) the bands as the 8-bit digital numbers they are (the TM tiles the reference reads are uint8) through
+    Context.upload_f32 — one byte per pixel over PCIe, widened on the device — and uint8 class ids back.
+    Never the bench `value`."""
     try:
         host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in bands]
         for h, b in zip(host, bands):
@@ -516,47 +602,48 @@ def pcie_inclusive(torch, device, bands, step, n_global):
         torch.cuda.synchronize()
         step()                                  # warm
         torch.cuda.synchronize()
+        dev = [torch.empty_like(b) for b in bands]
+        lab0, _ = step()
+        lab_host = torch.empty(lab0.numel(), dtype=lab0.dtype, pin_memory=True)   # the caller's result buffer, allocated once
+        del lab0
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for h, b in zip(host, bands):
-            b.copy_(h, non_blocking=True)
+        for h, d in zip(host, dev):
+            d.copy_(h, non_blocking=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        labels, _ = step()
+        labels, _ = step(bands=dev)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        lab_host = torch.empty(labels.numel(), dtype=labels.dtype, pin_memory=True)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
         lab_host.copy_(labels, non_blocking=True)
         torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        tot = (t1 - t0) + (t2 - t1) + (t4 - t3)
+        t3 = time.perf_counter()
         gb = sum(b.numel() * 4 for b in bands) / 1e9
-        out = {"value": round(n_global / 1e6 / tot, 2), "unit": "Mpixel/s", "h2d_ms": round((t1 - t0) * 1e3, 1), "h2d_GBs": round(gb / (t1 - t0), 1),
-               "compute_ms": round((t2 - t1) * 1e3, 1), "d2h_labels_ms": round((t4 - t3) * 1e3, 1),
-               "note": "7 bands pinned host -> HBM, one step, labels -> pinned host; transfers not overlapped with compute"}
-        # the synthetic bands are 8-bit digital numbers (like the TM tiles the reference reads): the same step with the bands
-        # crossing PCIe as uint8 and widened to float32 on the device (Context.upload_f32), labels back as uint8 class ids
-        del host
+        out = {"value": round(n_global / 1e6 / (t3 - t0), 2), "unit": "Mpixel/s", "pass_ms": round((t3 - t0) * 1e3, 1),
+               "h2d_ms": round((t1 - t0) * 1e3, 1), "h2d_GBs": round(gb / (t1 - t0), 1), "compute_ms": round((t2 - t1) * 1e3, 1),
+               "d2h_labels_ms": round((t3 - t2) * 1e3, 1),
+               "note": "one pass: 7 float32 bands pinned host -> HBM, one step, labels -> pinned host"}
+        del host, dev, lab_host, labels
         host8 = [torch.empty(b.numel(), dtype=torch.uint8, pin_memory=True) for b in bands]
         for h, b in zip(host8, bands):
             h.copy_(b.to(torch.uint8))
+        lab_host8 = torch.empty(bands[0].numel(), dtype=torch.uint8, pin_memory=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for h, b in zip(host8, bands):
-            b.copy_(h.to(device, non_blocking=True))       # uint8 upload, float32 on the device
+        dev8 = [ctx.upload_f32(h.numpy()) for h in host8]          # uint8 over PCIe, float32 on the device
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        labels, _ = step(bands=dev8)
         lab8 = labels.to(torch.uint8)
-        lab_host8 = torch.empty(lab8.numel(), dtype=torch.uint8, pin_memory=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        lab_host8.copy_(labels.to(torch.uint8), non_blocking=True)
+        lab_host8.copy_(lab8, non_blocking=True)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        tot8 = (t1 - t0) + out["compute_ms"] / 1e3 + (t3 - t2)
-        out["uint8_bands"] = {"value": round(n_global / 1e6 / tot8, 2), "h2d_and_widen_ms": round((t1 - t0) * 1e3, 1),
-                              "d2h_uint8_labels_ms": round((t3 - t2) * 1e3, 1)}
+        out["uint8_bands"] = {"value": round(n_global / 1e6 / (t3 - t0), 2), "pass_ms": round((t3 - t0) * 1e3, 1),
+                              "h2d_and_widen_ms": round((t1 - t0) * 1e3, 1), "compute_ms": round((t2 - t1) * 1e3, 1),
+                              "d2h_uint8_labels_ms": round((t3 - t2) * 1e3, 1),
+                              "note": "one pass: 7 uint8 bands pinned host -> HBM -> float32 planes, one step, uint8 class ids -> pinned host"}
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}

@@ -83,7 +83,7 @@ int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn f
 
 /* Per-kernel timing (HIP events on the context's stream, around each launch of the named
  * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices", "normalize", "quantize", "range",
- * "select", "kpp", "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
+ * "select", "kpp", "moment" (KMeans' column means), "labels" (uint8 -> int32 label plane), "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
  * of Sobel / Laplacian), "project", "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
 int rsseg_prof_enable(rsseg_ctx *ctx, int on);
 int rsseg_prof_reset(rsseg_ctx *ctx);

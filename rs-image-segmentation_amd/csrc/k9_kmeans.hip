@@ -1418,7 +1418,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         const bool own0 = li0 >= 0 && li0 < n;
         const size_t mom_bytes = sizeof(long long) * (size_t)nblk * F;
         if (n > 0) {
-            hipLaunchKernelGGL((km_moment<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            {
+                prof_scope ps(ctx, "moment");
+                hipLaunchKernelGGL((km_moment<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
+            }
             if (own0) hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li0, d_sp, d_row);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, mom_bytes, hipMemcpyDeviceToHost, st));
@@ -1861,6 +1864,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     }
     if (!strict) RSCHK(run_lloyd(false));
     if (n > 0) {
+        prof_scope ps(ctx, "labels");
         hipLaunchKernelGGL(km_labels_out, dim3((unsigned)std::min<int64_t>(4096, ceil_div64(n, KM_THREADS))), dim3(KM_THREADS), 0, st,
                            d_lab, d_labels, n);
         HIPCHK(ctx, hipGetLastError());
