@@ -85,6 +85,9 @@ int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn f
  * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices", "normalize", "quantize", "range",
  * "select", "kpp", "moment" (KMeans' column means), "labels" (uint8 -> int32 label plane), "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
  * of Sobel / Laplacian), "project", "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
+/* Number of times the library has made the host wait for the context's stream since the last reset (every result
+ * read-back, every all-reduce staged through the host): what a step costs in launch-pipeline bubbles. */
+int rsseg_ctx_host_syncs(rsseg_ctx *ctx, int reset, int64_t *count);
 int rsseg_prof_enable(rsseg_ctx *ctx, int on);
 int rsseg_prof_reset(rsseg_ctx *ctx);
 int rsseg_prof_get(rsseg_ctx *ctx, const char *name, double *total_ms, int64_t *launches);

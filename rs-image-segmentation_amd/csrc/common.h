@@ -58,7 +58,17 @@ struct rsseg_ctx {
     uint32_t *d_mm = nullptr;  // [RSSEG_MM_REPL][RSSEG_MM_PLANES][2] ordered keys {min, max}
     int mm_count = 0;
     double mm_min[8], mm_max[8];
+    // host synchronisations (hipStreamSynchronize / blocking copies) the library has made on this context (rsseg_ctx_host_syncs)
+    long long host_syncs = 0;
 };
+// every wait of the host for the context's stream goes through here, so that it is counted
+static inline hipError_t rs_sync(rsseg_ctx *ctx)
+{
+    ctx->host_syncs++;
+    return hipStreamSynchronize(ctx->stream);
+}
+// moves the last `count` recorded launches of family `from` to family `to` (speculative launches that turned out to be no-ops)
+void prof_retag(rsseg_ctx *ctx, const char *from, int count, const char *to);
 #define RSSEG_MM_PLANES 8
 #define RSSEG_MM_REPL 64   // replicas of the slot table, one 64-byte line each: a workgroup commits to replica blockIdx.x % 64
 int mm_begin(rsseg_ctx *ctx, int nplanes);   // reset the device slots before a producing launch (no-op when off)

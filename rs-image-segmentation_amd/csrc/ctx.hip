@@ -107,7 +107,7 @@ extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_all
 int ws_reserve(rsseg_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return RSSEG_OK;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     if (ctx->d_ws) HIPCHK(ctx, hipFree(ctx->d_ws));
     ctx->d_ws = nullptr;
     ctx->ws_bytes = 0;
@@ -121,7 +121,7 @@ int ws_reserve(rsseg_ctx *ctx, size_t bytes)
 int pin_reserve(rsseg_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->pin_bytes) return RSSEG_OK;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     if (ctx->h_pin) HIPCHK(ctx, hipHostFree(ctx->h_pin));
     ctx->h_pin = nullptr;
     ctx->pin_bytes = 0;
@@ -135,7 +135,7 @@ int pin_reserve(rsseg_ctx *ctx, size_t bytes)
 int stream_sync(rsseg_ctx *ctx)
 {
     if (ctx->async_mode) return RSSEG_OK;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     return RSSEG_OK;
 }
 
@@ -150,7 +150,7 @@ extern "C" int rsseg_ctx_sync(rsseg_ctx *ctx)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     return RSSEG_OK;
 }
 
@@ -170,7 +170,7 @@ int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, in
     int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
     if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_comm, ctx->d_comm, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     memcpy(host, ctx->h_comm, bytes);
     if (ctx->prof_on) {  // host wall time of the whole exchange (staging copies + collective), name "allreduce"
         prof_entry &e = ctx->prof["allreduce"];
@@ -217,7 +217,7 @@ int mm_end(rsseg_ctx *ctx, int nplanes)
     if (!ctx->mm_collect) return RSSEG_OK;
     uint32_t kr[2 * RSSEG_MM_PLANES * RSSEG_MM_REPL], k[2 * RSSEG_MM_PLANES];
     HIPCHK(ctx, hipMemcpyAsync(kr, ctx->d_mm, sizeof(kr), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     for (int i = 0; i < RSSEG_MM_PLANES; i++) {   // the replicas of a slot: smallest min key, largest max key
         k[2 * i] = 0xffffffffu;
         k[2 * i + 1] = 0;
@@ -268,6 +268,29 @@ prof_scope::~prof_scope()
     (void)hipEventRecord(b, ctx->stream);
     e->pending.emplace_back(a, b);
     e->launches++;
+}
+
+void prof_retag(rsseg_ctx *ctx, const char *from, int count, const char *to)
+{
+    if (!ctx->prof_on || count <= 0) return;
+    auto it = ctx->prof.find(from);
+    if (it == ctx->prof.end()) return;
+    prof_entry &src = it->second;
+    prof_entry &dst = ctx->prof[to];
+    while (count-- > 0 && !src.pending.empty()) {
+        dst.pending.push_back(src.pending.back());
+        src.pending.pop_back();
+        src.launches--;
+        dst.launches++;
+    }
+}
+
+extern "C" int rsseg_ctx_host_syncs(rsseg_ctx *ctx, int reset, int64_t *count)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (count) *count = ctx->host_syncs;
+    if (reset) ctx->host_syncs = 0;
+    return RSSEG_OK;
 }
 
 static void prof_drain(rsseg_ctx *ctx)

@@ -528,7 +528,7 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
     }
     if (!fits) groups.clear();
     forest_dev &fd = ctx->forest;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
     if (fd.d_nodes) HIPCHK(ctx, hipFree(fd.d_nodes));
     if (fd.d_leafval) HIPCHK(ctx, hipFree(fd.d_leafval));
     if (fd.d_treeoff) HIPCHK(ctx, hipFree(fd.d_treeoff));

@@ -238,7 +238,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpy2DAsync(h_hist_all, used * 8, d_hist_all, hist_bytes, used * 8, (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, rs_sync(ctx));
         RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * used), RSSEG_I64, RSSEG_SUM));
         bool small_ints = true;
         for (int p = 0; p < P; p++) small_ints = small_ints && h_hist_all[(size_t)p * used + 1] == 0 && h_hist_all[(size_t)p * used + 2] == 0;
@@ -294,7 +294,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         if (live == 0) break;
         if (pass > 0) {
             HIPCHK(ctx, hipMemcpyAsync(d_pre_all, h_pre.data(), sizeof(uint32_t) * h_pre.size(), hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_pre is rewritten in the next pass
+            HIPCHK(ctx, rs_sync(ctx));  // h_pre is rewritten in the next pass
         }
         HIPCHK(ctx, hipMemsetAsync(d_hist_all, 0, (size_t)P * hist_bytes, ctx->stream));
         for (int p = 0; p < P; p++) {
@@ -316,7 +316,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         for (int p = 0; p < P; p++) max_tab = std::max(max_tab, st[p].ndp);
         const size_t used_elems = 8 + (size_t)max_tab * SEL_BINS;  // per plane, compact on the host
         HIPCHK(ctx, hipMemcpy2DAsync(h_hist_all, used_elems * 8, d_hist_all, hist_bytes, used_elems * 8, (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, rs_sync(ctx));
         RSCHK(comm_allreduce_host(ctx, h_hist_all, (int64_t)((size_t)P * used_elems), RSSEG_I64, RSSEG_SUM));
         for (int p = 0; p < P; p++) {
             plane_state &S = st[p];

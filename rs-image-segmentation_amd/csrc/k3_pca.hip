@@ -346,7 +346,7 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
             }
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_ws, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, rs_sync(ctx));
             const float *hp = (const float *)ctx->h_pin;
             for (int g = 0; g < rgrid; g++)
                 for (int b = 0; b < nb; b++) {
@@ -404,7 +404,7 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
     HIPCHK(ctx, hipGetLastError());
     if (pcount) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * pcount, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, rs_sync(ctx));
     }
     typedef __int128 i128;
     long long lim[2 * PCA_NACC + 2];

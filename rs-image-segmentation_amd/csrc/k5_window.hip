@@ -597,7 +597,7 @@ static int filter_rows(rsseg_ctx *ctx, const char *what, const uint8_t *d_q, int
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_keys, 64 * RSSEG_MM_REPL, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, rs_sync(ctx));
         uint32_t kmn = 0xffffffffu, kmx = 0;
         for (int r = 0; r < RSSEG_MM_REPL; r++) {
             kmn = std::min(kmn, ((const uint32_t *)ctx->h_pin)[16 * r]);

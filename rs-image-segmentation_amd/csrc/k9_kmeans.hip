@@ -487,8 +487,10 @@ template <typename T, int KMAX, int FR, bool UPDATE>
 __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k, int64_t n,
                                                        const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
                                                        const T *__restrict__ csq, uint8_t *__restrict__ labels,
-                                                       long long *__restrict__ partial, int64_t nchunks, int ncopies)
+                                                       long long *__restrict__ partial, int64_t nchunks, int ncopies,
+                                                       const int *__restrict__ done)
 {
+    if (done && *done) return;   // a speculatively enqueued iteration behind the one that converged (kl_update)
     constexpr int PXL = vt<T>::PXL;
     constexpr int TILE = KM_THREADS * PXL;
     extern __shared__ __align__(16) char smem[];
@@ -796,8 +798,10 @@ template <typename T, int KMAX, bool UPDATE>
 __global__ __launch_bounds__(KM_THREADS) void km_lloyd_blk(planes_t pl, int F, int k, int64_t n,
                                                            const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
                                                            const T *__restrict__ csq, uint8_t *__restrict__ labels,
-                                                           long long *__restrict__ partial, int64_t nchunks, int ncopies)
+                                                           long long *__restrict__ partial, int64_t nchunks, int ncopies,
+                                                           const int *__restrict__ done)
 {
+    if (done && *done) return;
     constexpr int PXL = vt<T>::PXL;
     constexpr int TILE = KM_THREADS * PXL;
     extern __shared__ __align__(16) char smem[];
@@ -1007,8 +1011,9 @@ __global__ __launch_bounds__(KM_THREADS) void km_farthest(planes_t pl, int F, in
 
 // column sums of partial[M][nchunks] -> out[M][2] = {sum of (v >> 32), sum of (v & 0xffffffff)}
 __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__restrict__ partial, int64_t nchunks,
-                                                            long long *__restrict__ out)
+                                                            long long *__restrict__ out, const int *__restrict__ done)
 {
+    if (done && *done) return;
     const int m = blockIdx.x;
     long long hi = 0, lo = 0;
     for (int64_t c = threadIdx.x; c < nchunks; c += KM_THREADS) {
@@ -1030,6 +1035,144 @@ __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__
 __global__ __launch_bounds__(KM_THREADS) void km_labels_out(const uint8_t *__restrict__ lab, int32_t *__restrict__ out, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * KM_THREADS) out[i] = lab[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lloyd iterations without the host in the loop.  The state of _kmeans_single_lloyd lives in device memory; per
+// iteration the host enqueues  kl_prepare -> km_lloyd<update> -> km_reduce_cols -> [all-reduce hook] -> kl_update  and
+// looks at the state only every few iterations.  kl_update does what sklearn does between two E-steps
+// (_average_centers, _center_shift, the two stopping rules of _kmeans.py:717-732) with the same operations in the same
+// order as the host code it replaces (every T operation is one IEEE operation: -ffp-contract=off), and raises `done`;
+// the iterations already enqueued behind it see the flag and return at once.  An EMPTY cluster needs
+// _relocate_empty_clusters_dense, which stays a host path: kl_update then parks the reduced sums of that iteration
+// (done = 3) and the host loop takes over from exactly there.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct lloyd_state {
+    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];  // centres_old of the next E-step
+    T tol;
+    int it;        // iterations completed
+    int done;      // 0 running | 1 labels unchanged (strict) | 2 centre shift <= tol | 3 empty cluster: host takes over | 4 max_iter
+    int max_iter;
+    int pad;
+};
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __fsqrt_rn(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return __dsqrt_rn(x); }
+
+// cenT[f * KMAX + j] = C[j][f] (zeros elsewhere), csq[j] = fma chain of C[j][f]^2 over f — row_norms(centers, squared=True)
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kl_prepare(const lloyd_state<T> *__restrict__ st, int k, int F, int KMAX, T *__restrict__ cenT,
+                                                         int force)
+{
+    if (st->done && !force) return;
+    T *csq = cenT + (size_t)KMAX * RSSEG_MAX_FEATURES;
+    for (int i = threadIdx.x; i < KMAX * RSSEG_MAX_FEATURES + KMAX; i += KM_THREADS) {
+        T v = (T)0;
+        if (i < KMAX * RSSEG_MAX_FEATURES) {
+            const int f = i / KMAX, j = i - f * KMAX;
+            if (j < k && f < F) v = st->C[j][f];
+        } else {
+            const int j = i - KMAX * RSSEG_MAX_FEATURES;
+            if (j < k)
+                for (int f = 0; f < F; f++) v = tfma<T>(st->C[j][f], st->C[j][f], v);
+        }
+        cenT[i] = v;
+    }
+}
+
+__device__ __forceinline__ i128 dev_limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
+template <typename T> __device__ __forceinline__ T dev_fixed_to_T(i128 s) { return (T)((double)s * (1.0 / 1099511627776.0)); }
+
+template <typename T> __device__ T dev_pairwise_sum(const T *a, int n)   // numpy pairwise sum, n <= 128
+{
+    if (n < 8) {
+        T res = (T)0;
+        for (int i = 0; i < n; i++) res = res + a[i];
+        return res;
+    }
+    T r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] = r[j] + a[i + j];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+}
+
+// red: [M][2] limb sums of this iteration over all ranks (km_reduce_cols, all-reduced), M = KMAX * F + KMAX + 1
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *__restrict__ st, int k, int F, int KMAX, const long long *__restrict__ red,
+                                                        long long *__restrict__ red_saved)
+{
+    if (st->done) return;
+    __shared__ long long cnt[RSSEG_MAX_CLUSTERS];
+    __shared__ T shift2[RSSEG_MAX_CLUSTERS];
+    __shared__ int n_empty;
+    const int M = KMAX * F + KMAX + 1;
+    if (threadIdx.x == 0) n_empty = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < k) {
+        const long long c = (long long)dev_limbs(red[2 * (KMAX * F + threadIdx.x)], red[2 * (KMAX * F + threadIdx.x) + 1]);
+        cnt[threadIdx.x] = c;
+        if (c == 0) atomicAdd(&n_empty, 1);
+    }
+    __syncthreads();
+    if (n_empty > 0) {   // _relocate_empty_clusters_dense is a host path: keep this iteration's sums for it
+        for (int i = threadIdx.x; i < 2 * M; i += KM_THREADS) red_saved[i] = red[i];
+        __syncthreads();
+        if (threadIdx.x == 0) st->done = 3;
+        return;
+    }
+    // _average_centers, then _center_shift per cluster (one thread per cluster walks its F columns in the host's order)
+    if ((int)threadIdx.x < k) {
+        const int j = threadIdx.x;
+        const T w = (T)cnt[j];
+        const T alpha = (T)(1.0 / (double)w);
+        T result = (T)0;
+        const int n4 = F / 4, rem = F % 4;
+        int f = 0;
+        T cn[4];
+        for (int g = 0; g < n4; g++, f += 4) {
+            T d[4];
+            for (int u = 0; u < 4; u++) {
+                const T sT = dev_fixed_to_T<T>(dev_limbs(red[2 * (j * F + f + u)], red[2 * (j * F + f + u) + 1]));
+                cn[u] = sT * alpha;
+                d[u] = cn[u] - st->C[j][f + u];
+            }
+            const T t0 = d[0] * d[0], t1 = d[1] * d[1], t2 = d[2] * d[2], t3 = d[3] * d[3];
+            const T g1 = t0 + t1;
+            const T g2 = g1 + t2;
+            const T g4 = g2 + t3;
+            result = result + g4;
+            for (int u = 0; u < 4; u++) st->C[j][f + u] = cn[u];
+        }
+        for (int r = 0; r < rem; r++, f++) {
+            const T sT = dev_fixed_to_T<T>(dev_limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]));
+            const T c1 = sT * alpha;
+            const T d = c1 - st->C[j][f];
+            const T t = d * d;
+            result = result + t;
+            st->C[j][f] = c1;
+        }
+        const T sh = t_sqrt<T>(result);
+        shift2[j] = sh * sh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long changed = (long long)dev_limbs(red[2 * (KMAX * F + KMAX)], red[2 * (KMAX * F + KMAX) + 1]);
+        const int it = st->it + 1;
+        st->it = it;
+        int done = 0;
+        if (changed == 0) done = 1;
+        else {
+            const T tot = dev_pairwise_sum<T>(shift2, k);
+            if (tot <= st->tol) done = 2;
+            else if (it >= st->max_iter) done = 4;
+        }
+        st->done = done;
+    }
 }
 
 // ================================================================================================
@@ -1171,7 +1314,7 @@ i128 limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
 
 template <typename T, int KMAX, int FR>
 int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
+                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done)
 {
     if (update) {
         // per device: the dynamic-LDS limit already granted to this instantiation (contexts of several threads may race here)
@@ -1187,21 +1330,21 @@ int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plan
             }
         }
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies);
+                           cenT, csq, labels, partial, nchunks, ncopies, done);
     } else {
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies);
+                           cenT, csq, labels, partial, nchunks, ncopies, done);
     }
     return RSSEG_OK;
 }
 
 template <typename T, int KMAX>
 int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies)
+                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done)
 {
-    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
-    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
-    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies);
+    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
+    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
+    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
     // 32 < F <= RSSEG_MAX_FEATURES: the feature-blocked kernel
     if (update) {
         static std::mutex mu;
@@ -1216,10 +1359,10 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
             }
         }
         hipLaunchKernelGGL((km_lloyd_blk<T, KMAX, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies);
+                           cenT, csq, labels, partial, nchunks, ncopies, done);
     } else {
         hipLaunchKernelGGL((km_lloyd_blk<T, KMAX, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies);
+                           cenT, csq, labels, partial, nchunks, ncopies, done);
     }
     return RSSEG_OK;
 }
@@ -1305,6 +1448,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_samp = carve(sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES));
     const size_t o_qv = carve(sizeof(unsigned long long) * KPP_MAXL * (size_t)CHUNK);
     const size_t o_red = carve(sizeof(long long) * 2 * M);
+    const size_t o_redsave = carve(sizeof(long long) * 2 * M);
+    const size_t o_lst = carve(sizeof(lloyd_state<T>));
     const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
     const size_t o_mom = carve(sizeof(long long) * (size_t)nblk * F);
     const size_t o_part = carve(sizeof(long long) * std::max<size_t>((size_t)M, KPP_MAXL) * (size_t)nchunks);
@@ -1314,7 +1459,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F + sizeof(double) * RSSEG_MAX_FEATURES + 64,
                                               sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
-                                              sizeof(long long) * 2 * (size_t)M, (size_t)65536});
+                                              sizeof(long long) * 2 * (size_t)M + sizeof(T) * RSSEG_MAX_CLUSTERS * RSSEG_MAX_FEATURES, (size_t)65536});
     // small host-to-device uploads (candidate rows, centres) go through a ring of pinned slots behind the read-back area:
     // the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came from dies
     // (a slot is reused four uploads later; every k-means++ round and every Lloyd iteration synchronises in between)
@@ -1337,6 +1482,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     double *d_samp = (double *)(ws + o_samp);
     unsigned long long *d_qv = (unsigned long long *)(ws + o_qv);
     long long *d_red = (long long *)(ws + o_red);
+    long long *d_redsave = (long long *)(ws + o_redsave);
+    lloyd_state<T> *d_lst = (lloyd_state<T> *)(ws + o_lst);
     T *d_mm = (T *)(ws + o_mm);
     long long *d_mom = (long long *)(ws + o_mom);
     long long *d_part = (long long *)(ws + o_part);
@@ -1360,7 +1507,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             hipLaunchKernelGGL((km_minmax<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_mm, d_mm + (size_t)nblk * F);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mm, sizeof(T) * 2 * (size_t)nblk * F, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, rs_sync(ctx));
         }
         const T *hmn = (const T *)ctx->h_pin, *hmx = hmn + (size_t)nblk * F;
         double mm[2 * RSSEG_MAX_FEATURES + RSSEG_MAX_RANKS];
@@ -1426,7 +1573,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, mom_bytes, hipMemcpyDeviceToHost, st));
             if (own0) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + mom_bytes, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, rs_sync(ctx));
         }
         long long lim[3 * RSSEG_MAX_FEATURES];
         const long long *hp = (const long long *)ctx->h_pin;
@@ -1477,7 +1624,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li, d_sp, d_row);
                 HIPCHK(ctx, hipGetLastError());
                 HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
+                HIPCHK(ctx, rs_sync(ctx));
                 for (int f = 0; f < F; f++) buf[l * F + f] = (double)((const T *)ctx->h_pin)[f];
             }
         }
@@ -1510,7 +1657,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     auto pull_partials = [&](int rows) -> int {
         if (n > 0) {
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)rows * nchunks, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, rs_sync(ctx));
             memcpy(h_part.data(), ctx->h_pin, sizeof(long long) * (size_t)rows * nchunks);
         } else {
             std::fill(h_part.begin(), h_part.end(), 0ull);
@@ -1626,7 +1773,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             hipLaunchKernelGGL((km_kpp_sample<T>), dim3(L), dim3(KM_THREADS), 0, st, pl, F, d_sp, (const unsigned long long *)d_qv, sa, d_samp);
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_samp, sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
+            HIPCHK(ctx, rs_sync(ctx));
             const double *hs = (const double *)ctx->h_pin;
             for (int l = 0; l < L; l++)
                 if (sa.mode[l] != 0)
@@ -1690,39 +1837,43 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     while (ncopies > 1 && sizeof(long long) * (size_t)ncopies * km_copy_stride(KMAX, F) > 48 * 1024) ncopies >>= 1;
     const size_t lds = sizeof(long long) * (size_t)ncopies * km_copy_stride(KMAX, F);
     if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
-    auto run_lloyd = [&](bool update) -> int {
-        // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
-        T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS + RSSEG_MAX_CLUSTERS];  // [MAX_FEATURES][KMAX] centres, then KMAX norms
-        T *csq = cenT + (size_t)KMAX * RSSEG_MAX_FEATURES;
-        memset(cenT, 0, sizeof(cenT));
-        for (int j = 0; j < k; j++) {
-            T a = (T)0;
-            for (int f = 0; f < F; f++) {
-                cenT[f * KMAX + j] = C[j][f];
-                a = std::is_same<T, float>::value ? (T)fmaf((float)C[j][f], (float)C[j][f], (float)a) : (T)std::fma((double)C[j][f], (double)C[j][f], (double)a);
+    // one E-step (+ per-cluster sums when `update`).  from_state: the centres come from the device state (kl_prepare builds
+    // their transposed copy and norms; `done`-guarded unless forced); otherwise from the host array C.
+    auto run_lloyd = [&](bool update, bool from_state, bool force) -> int {
+        if (from_state) {
+            hipLaunchKernelGGL((kl_prepare<T>), dim3(1), dim3(KM_THREADS), 0, st, (const lloyd_state<T> *)d_lst, k, F, KMAX, d_cen, force ? 1 : 0);
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
+            T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS + RSSEG_MAX_CLUSTERS];  // [MAX_FEATURES][KMAX] centres, then KMAX norms
+            T *csq = cenT + (size_t)KMAX * RSSEG_MAX_FEATURES;
+            memset(cenT, 0, sizeof(cenT));
+            for (int j = 0; j < k; j++) {
+                T a = (T)0;
+                for (int f = 0; f < F; f++) {
+                    cenT[f * KMAX + j] = C[j][f];
+                    a = std::is_same<T, float>::value ? (T)fmaf((float)C[j][f], (float)C[j][f], (float)a) : (T)std::fma((double)C[j][f], (double)C[j][f], (double)a);
+                }
+                csq[j] = a;
             }
-            csq[j] = a;
+            static_assert(sizeof(cenT) <= UP_SLOT, "upload slot too small");
+            HIPCHK(ctx, upload(d_cen, cenT, sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX)));
         }
-        static_assert(sizeof(cenT) <= UP_SLOT, "upload slot too small");
-        HIPCHK(ctx, upload(d_cen, cenT, sizeof(T) * ((size_t)KMAX * RSSEG_MAX_FEATURES + KMAX)));
+        const int *dflag = (from_state && !force) ? &d_lst->done : nullptr;
         if (n > 0) {
             {
                 prof_scope ps(ctx, "lloyd");
                 const size_t l2 = update ? lds : 0;
                 int lrc;
                 switch (KMAX) {
-                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
-                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
-                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
-                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies); break;
+                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
+                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
+                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
+                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
                 }
                 if (lrc != RSSEG_OK) return lrc;
             }
             HIPCHK(ctx, hipGetLastError());
-            if (update) {
-                hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, d_part, nchunks, d_red);
-                HIPCHK(ctx, hipGetLastError());
-            }
         }
         return RSSEG_OK;
     };
@@ -1731,16 +1882,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     bool strict = false;
     int it = 0, relocated = 0;
     std::vector<long long> red((size_t)2 * M);
-    for (it = 0; it < max_iter; it++) {
-        RSCHK(run_lloyd(true));
-        if (n > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_red, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            memcpy(red.data(), ctx->h_pin, sizeof(long long) * 2 * M);
-        } else {
-            std::fill(red.begin(), red.end(), 0ll);
-        }
-        RSCHK(comm_allreduce_host(ctx, red.data(), 2 * M, RSSEG_I64, RSSEG_SUM));
+
+    // What _kmeans_single_lloyd does between two E-steps, on the host: used from the iteration in which a cluster ran
+    // empty (the device loop hands over with that iteration's reduced sums in `red`).  Returns 1 when the loop ends.
+    auto host_finish_iteration = [&]() -> int {
         int64_t cnt[RSSEG_MAX_CLUSTERS];
         int n_empty = 0;
         for (int j = 0; j < k; j++) {
@@ -1749,9 +1894,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         }
         const int64_t changed = (int64_t)limbs(red[2 * (KMAX * F + KMAX)], red[2 * (KMAX * F + KMAX) + 1]);
         // exact per-cluster sums as 128-bit integers
-        i128 S[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
+        std::vector<i128> Sv((size_t)RSSEG_MAX_CLUSTERS * RSSEG_MAX_FEATURES);
+        auto S = [&](int j, int f) -> i128 & { return Sv[(size_t)j * RSSEG_MAX_FEATURES + f]; };
         for (int j = 0; j < k; j++)
-            for (int f = 0; f < F; f++) S[j][f] = limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]);
+            for (int f = 0; f < F; f++) S(j, f) = limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]);
         if (n_empty > 0) {
             // _relocate_empty_clusters_dense: the e-th empty cluster takes the e-th farthest pixel
             taken_t tk;
@@ -1773,7 +1919,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                     }
                     HIPCHK(ctx, hipGetLastError());
                     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * 2 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
-                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    HIPCHK(ctx, rs_sync(ctx));
                     const T *hd = (const T *)ctx->h_pin;
                     const long long *hi = (const long long *)ctx->h_pin + nchunks;
                     for (int64_t c2 = 0; c2 < nchunks; c2++)
@@ -1792,15 +1938,15 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 double oldlab = 0.0;
                 if (far >= offset && far < offset + n) {
                     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lab + (far - offset), 1, hipMemcpyDeviceToHost, st));
-                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    HIPCHK(ctx, rs_sync(ctx));
                     oldlab = (double)((const uint8_t *)ctx->h_pin)[0];
                 }
                 RSCHK(comm_allreduce_host(ctx, &oldlab, 1, RSSEG_F64, RSSEG_SUM));
                 const int oj = (int)oldlab;
                 for (int f = 0; f < F; f++) {
                     const i128 q = (i128)llrint((double)rows[0][f] * 1099511627776.0);
-                    S[oj][f] -= q;
-                    S[j][f] = q;
+                    S(oj, f) -= q;
+                    S(j, f) = q;
                 }
                 cnt[j] = 1;
                 cnt[oj] -= 1;
@@ -1818,7 +1964,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             volatile T w = (T)cnt[j];
             volatile T alpha = (T)(1.0 / (double)w);
             for (int f = 0; f < F; f++) {
-                volatile T sT = fixed_to_T<T>(S[j][f]);
+                volatile T sT = fixed_to_T<T>(S(j, f));
                 volatile T cnew = sT * alpha;
                 Cnew[j][f] = cnew;
             }
@@ -1851,25 +1997,103 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             shift2[j] = s2;
         }
         memcpy(C, Cnew, sizeof(C));
+        it++;
         if (changed == 0) {
             strict = true;
-            it++;
-            break;
+            return 1;
         }
         const T tot = np_pairwise_sum<T>(shift2, k);
-        if (tot <= tol) {
-            it++;
-            break;
+        if (tot <= tol) return 1;
+        return it >= max_iter ? 1 : 0;
+    };
+
+    // ---- device-resident loop: batches of speculatively enqueued iterations, one look at the state per batch ----
+    long long *d_sums = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;   // where km_reduce_cols leaves the limb sums
+    if (ctx->world > 1 && sizeof(long long) * 2 * (size_t)M > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small");
+    {
+        lloyd_state<T> h_st;
+        memset(&h_st, 0, sizeof(h_st));
+        memcpy(h_st.C, C, sizeof(C));
+        h_st.tol = tol;
+        h_st.max_iter = max_iter;
+        static_assert(sizeof(h_st) <= UP_SLOT, "upload slot too small");
+        HIPCHK(ctx, upload(d_lst, &h_st, sizeof(h_st)));
+    }
+    bool finished = false, host_mode = false;
+    int batch = 4;
+    while (!finished && !host_mode) {
+        const int todo = std::min(batch, max_iter - it);
+        for (int b = 0; b < todo; b++) {
+            RSCHK(run_lloyd(true, true, false));
+            hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_sums, (const int *)&d_lst->done);
+            HIPCHK(ctx, hipGetLastError());
+            if (ctx->world > 1) {   // stream-ordered: no staging copy, no host synchronisation (include/rsseg.h, rsseg_allreduce_fn)
+                const auto t0c = std::chrono::steady_clock::now();
+                if (n <= 0) HIPCHK(ctx, hipMemsetAsync(d_sums, 0, sizeof(long long) * 2 * M, st));
+                const int rc = ctx->allreduce(ctx->comm_user, 0, 2 * (int64_t)M, RSSEG_I64, RSSEG_SUM);
+                if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
+                if (ctx->prof_on) {
+                    prof_entry &e = ctx->prof["allreduce"];
+                    e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
+                    e.launches++;
+                }
+            }
+            hipLaunchKernelGGL((kl_update<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, k, F, KMAX, (const long long *)d_sums, d_redsave);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        // one look at the state
+        int *hflags = (int *)ctx->h_pin;
+        HIPCHK(ctx, hipMemcpyAsync(hflags, &d_lst->it, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, rs_sync(ctx));
+        const int it_new = hflags[0], done = hflags[1];
+        prof_retag(ctx, "lloyd", todo - (it_new - it) - (done == 3 ? 1 : 0), "lloyd_noop");   // launches that returned at once
+        it = it_new;
+        if (done == 1 || done == 2 || done == 4) {
+            strict = done == 1;
+            finished = true;
+        } else if (done == 3) {
+            host_mode = true;
+        } else if (it >= max_iter) {
+            finished = true;
+        }
+        batch = 8;
+    }
+    if (host_mode || finished) {   // the centres the device loop ended with (the host continues from them, or reports them)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lst->C, sizeof(C), hipMemcpyDeviceToHost, st));
+        if (host_mode) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + sizeof(C), d_redsave, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, rs_sync(ctx));
+        memcpy(C, ctx->h_pin, sizeof(C));
+        if (host_mode) memcpy(red.data(), ctx->h_pin + sizeof(C), sizeof(long long) * 2 * M);
+    }
+    if (host_mode) {
+        // the iteration in which a cluster ran empty: its E-step and its (all-reduced) sums exist, the centres the kernels
+        // used (d_cen) are still those of that E-step — finish it here, then iterate on the host
+        int end = host_finish_iteration();
+        if (end < 0) return end;
+        while (!end) {
+            RSCHK(run_lloyd(true, false, true));
+            if (n > 0) {
+                hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_red, (const int *)nullptr);
+                HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_red, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, rs_sync(ctx));
+                        memcpy(red.data(), ctx->h_pin, sizeof(long long) * 2 * M);
+            } else {
+                std::fill(red.begin(), red.end(), 0ll);
+            }
+            RSCHK(comm_allreduce_host(ctx, red.data(), 2 * M, RSSEG_I64, RSSEG_SUM));
+            end = host_finish_iteration();
+            if (end < 0) return end;
         }
     }
-    if (!strict) RSCHK(run_lloyd(false));
+    if (!strict) RSCHK(run_lloyd(false, false, true));
     if (n > 0) {
         prof_scope ps(ctx, "labels");
         hipLaunchKernelGGL(km_labels_out, dim3((unsigned)std::min<int64_t>(4096, ceil_div64(n, KM_THREADS))), dim3(KM_THREADS), 0, st,
                            d_lab, d_labels, n);
         HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, rs_sync(ctx));
     if (centers_out)
         for (int j = 0; j < k; j++)
             for (int f = 0; f < F; f++) {

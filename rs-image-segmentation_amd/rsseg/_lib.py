@@ -50,6 +50,7 @@ SIGNATURES = {
     "rsseg_ctx_set_comm": (_int, [_vp, _int, _int, ALLREDUCE_FN, _vp, _vp, C.c_size_t]),
     "rsseg_ctx_set_async": (_int, [_vp, _int]),
     "rsseg_ctx_sync": (_int, [_vp]),
+    "rsseg_ctx_host_syncs": (_int, [_vp, _int, C.POINTER(_i64)]),
     "rsseg_prof_enable": (_int, [_vp, _int]),
     "rsseg_prof_reset": (_int, [_vp]),
     "rsseg_prof_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

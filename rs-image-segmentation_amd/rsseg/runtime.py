@@ -235,6 +235,12 @@ class Context:
     def prof_reset(self):
         self._chk(self.lib.rsseg_prof_reset(self.h))
 
+    def host_syncs(self, reset: bool = False) -> int:
+        """How often the library made the host wait for this context's stream since the last reset."""
+        n = C.c_int64(0)
+        self._chk(self.lib.rsseg_ctx_host_syncs(self.h, int(reset), C.byref(n)))
+        return n.value
+
     def prof_get(self, name: str) -> Tuple[float, int]:
         ms, cnt = C.c_double(0), C.c_int64(0)
         self._chk(self.lib.rsseg_prof_get(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
