@@ -363,6 +363,7 @@ def main():
         labels, meta = step()
     ctx.prof_enable(True)
     ctx.prof_reset()
+    ctx.host_syncs(reset=True)
     if getattr(ctx, "_aux", None) is not None:
         ctx._aux.prof_enable(True)
         ctx._aux.prof_reset()
@@ -391,6 +392,7 @@ def main():
         if cnt:
             fams[fam] = (ms, cnt)
     comm_ms, comm_cnt = ctx.prof_get("allreduce")
+    host_syncs = ctx.host_syncs()
     ctx.prof_enable(False)
 
     # ---- side measurements (rank 0, N = 1): GLCM step 7, the other synthetic raster, north_star's literal configuration,
@@ -516,6 +518,7 @@ def main():
                        "data_kind": args.data,
                        "parallelism": (f"one raster row-striped x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of histograms / PCA sums / KMeans partials / Sobel max"
                                        if world > 1 else "single GPU"),
+                       "host_syncs_per_step": round(host_syncs / args.steps, 1),
                        "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3),
                        **extras},
             "roofline": roof, "cpu_baseline": cpu,

@@ -356,9 +356,10 @@ struct kpp_sample_args {
 template <typename T>
 __global__ __launch_bounds__(KM_THREADS) void km_kpp_chunkq(planes_t pl, int F, const scaler_t<T> *__restrict__ sp,
                                                             const double *__restrict__ candT, const double *__restrict__ cc,
-                                                            const T *__restrict__ closest, kpp_sample_args a,
+                                                            const T *__restrict__ closest, const kpp_sample_args *__restrict__ ap,
                                                             unsigned long long *__restrict__ qv)
 {
+    const kpp_sample_args &a = *ap;
     const int l = blockIdx.y;
     if (a.mode[l] != 1) return;
     const int64_t c0 = a.c0[l], cn = a.cn[l];
@@ -388,9 +389,10 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_chunkq(planes_t pl, int F, 
 // step 2 (one workgroup per candidate): two-level search over the exact prefix sums, then the row of the pixel found
 template <typename T>
 __global__ __launch_bounds__(KM_THREADS) void km_kpp_sample(planes_t pl, int F, const scaler_t<T> *__restrict__ sp,
-                                                            const unsigned long long *__restrict__ qv, kpp_sample_args a,
+                                                            const unsigned long long *__restrict__ qv, const kpp_sample_args *__restrict__ ap,
                                                             double *__restrict__ out)
 {
+    const kpp_sample_args &a = *ap;
     const int l = blockIdx.x;
     double *o = out + (size_t)l * (1 + RSSEG_MAX_FEATURES);
     if (a.mode[l] == 0) return;
@@ -1010,8 +1012,9 @@ __global__ __launch_bounds__(KM_THREADS) void km_farthest(planes_t pl, int F, in
 }
 
 // column sums of partial[M][nchunks] -> out[M][2] = {sum of (v >> 32), sum of (v & 0xffffffff)}
+// row m lands in out[2 * (m * ostride + ooff)] (ostride = 1, ooff = 0: consecutive rows)
 __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__restrict__ partial, int64_t nchunks,
-                                                            long long *__restrict__ out, const int *__restrict__ done)
+                                                            long long *__restrict__ out, const int *__restrict__ done, int ostride, int ooff)
 {
     if (done && *done) return;
     const int m = blockIdx.x;
@@ -1027,8 +1030,8 @@ __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__
     if (lane_id() == 0) { sh[threadIdx.x >> 6] = hi; sl[threadIdx.x >> 6] = lo; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2 * m] = sh[0] + sh[1] + sh[2] + sh[3];
-        out[2 * m + 1] = sl[0] + sl[1] + sl[2] + sl[3];
+        out[2 * (m * ostride + ooff)] = sh[0] + sh[1] + sh[2] + sh[3];
+        out[2 * (m * ostride + ooff) + 1] = sl[0] + sl[1] + sl[2] + sl[3];
     }
 }
 
@@ -1047,14 +1050,29 @@ __global__ __launch_bounds__(KM_THREADS) void km_labels_out(const uint8_t *__res
 // _relocate_empty_clusters_dense, which stays a host path: kl_update then parks the reduced sums of that iteration
 // (done = 3) and the host loop takes over from exactly there.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct lloyd_state {
-    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];  // centres_old of the next E-step
+template <typename T> struct km_state {
+    // Lloyd (kl_prepare / kl_update)
+    T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];  // k-means++: the centres chosen so far; Lloyd: centres_old of the next E-step
     T tol;
     int it;        // iterations completed
     int done;      // 0 running | 1 labels unchanged (strict) | 2 centre shift <= tol | 3 empty cluster: host takes over | 4 max_iter
     int max_iter;
-    int pad;
+    int best;      // k-means++: the row of the chunk-partial table that is the current prefix table (the chosen candidate's)
+    // geometry of the (possibly row-sharded) raster
+    long long n_all[RSSEG_MAX_RANKS];
+    long long N, offset, n_local, nchunks;
+    int rank, world, k, F, L, last_rank;
+    double tol_in;
+    // k-means++ (_kmeans.py:213-270)
+    double uniforms[(RSSEG_MAX_CLUSTERS - 1) * KPP_MAXL];   // rng.uniform(size=L) of every round, drawn by the host up front
+    long long init_idx[RSSEG_MAX_CLUSTERS];
+    long long cand_idx[KPP_MAXL];
+    T rows[KPP_MAXL][RSSEG_MAX_FEATURES];                   // this round's candidate rows
+    T mean[RSSEG_MAX_FEATURES];
+    T current_pot;
+    u128 rank_tot[RSSEG_MAX_RANKS];                         // every rank's total of the closest-distance sums
 };
+template <typename T> using lloyd_state = km_state<T>;
 
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __fsqrt_rn(x); }
@@ -1173,6 +1191,234 @@ __global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *__restri
         }
         st->done = done;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ without the host in the loop: what the host did between the sweeps (means, tolerance, the D^2 sampling of a
+// round's candidates, the choice of the best candidate) as single-workgroup kernels over km_state, same operations in
+// the same order.  Values that cross ranks sit in `x` (the communication buffer when world > 1) and are all-reduced
+// by the hook between two of these kernels, stream-ordered.
+// ------------------------------------------------------------------------------------------------
+// ceil(r * 2^40) for a finite r >= 0 as an exact integer (the host computed ceill((long double)r * 2^40))
+__device__ __forceinline__ u128 kc_ceil_scaled(double r)
+{
+    if (!(r > 0.0)) return (u128)0;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(r);
+    const int be = (int)((b >> 52) & 0x7ff);
+    unsigned long long m = b & 0xfffffffffffffull;
+    int e;
+    if (be == 0) e = -1074;                    // subnormal
+    else { m |= 1ull << 52; e = be - 1075; }
+    const int sft = e + 40;
+    if (sft >= 0) return (u128)m << sft;
+    const int sh = -sft;
+    if (sh >= 64) return (u128)1;              // 0 < r * 2^40 < 1
+    const unsigned long long q = m >> sh, rem = m & ((1ull << sh) - 1ull);
+    return (u128)q + (rem ? 1 : 0);
+}
+__device__ __forceinline__ u128 kc_ulimbs(long long hi, long long lo) { return ((u128)(unsigned long long)hi << 32) + (u128)(unsigned long long)lo; }
+
+// per-feature sums of the scaled matrix from km_moment's block partials, and the (not yet centred) row of the first centre
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_mean_pack(const km_state<T> *__restrict__ st, const long long *__restrict__ mom, int nblk,
+                                                           const T *__restrict__ row, int own0, long long *__restrict__ x)
+{
+    const int F = st->F, f = threadIdx.x;
+    if (f >= F) return;
+    i128 s = 0;
+    if (st->n_local > 0)
+        for (int b = 0; b < nblk; b++) s += mom[(size_t)f * nblk + b];
+    x[2 * f] = (long long)(s >> 32);
+    x[2 * f + 1] = (long long)(s & 0xffffffffLL);
+    double rv = own0 ? (double)row[f] : 0.0;
+    if (rv == 0.0) rv = 0.0;   // -0.0 would not survive the integer sum as a zero
+    x[2 * F + f] = __double_as_longlong(rv);
+}
+
+// X.mean(axis=0) (-> the scaler on the device), the first centre, and the candidate table of the first k-means++ sweep
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_mean_apply(km_state<T> *__restrict__ st, scaler_t<T> *__restrict__ sp, const long long *__restrict__ x,
+                                                            double *__restrict__ candT)
+{
+    const int F = st->F;
+    double *cc = candT + (size_t)KPP_STRIDE * RSSEG_MAX_FEATURES;
+    for (int i = threadIdx.x; i < KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE; i += KM_THREADS) candT[i] = 0.0;
+    __syncthreads();
+    const T Nt = (T)st->N;
+    if ((int)threadIdx.x < F) {
+        const int f = threadIdx.x;
+        const T sT = dev_fixed_to_T<T>(dev_limbs(x[2 * f], x[2 * f + 1]));
+        const T m = sT / Nt;
+        sp->mean[f] = m;
+        st->mean[f] = m;
+        const T raw = (T)__longlong_as_double(x[2 * F + f]);
+        const T c0 = raw - m;     // the centring the sweeps apply: fl(fl(fl(x * scale) + min) - mean)
+        st->C[0][f] = c0;
+        candT[f * KPP_STRIDE] = (double)c0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int f = 0; f < F; f++) a = fma((double)st->C[0][f], (double)st->C[0][f], a);
+        cc[0] = a;
+    }
+}
+
+// tol = mean(np.var(X, axis=0)) * tol_in, every rank's total of the first potential, current_pot
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_tol(km_state<T> *__restrict__ st, const long long *__restrict__ x)
+{
+    __shared__ T var[RSSEG_MAX_FEATURES];
+    const int F = st->F;
+    const T Nt = (T)st->N;
+    if ((int)threadIdx.x < F) {
+        const T sT = dev_fixed_to_T<T>(dev_limbs(x[2 * threadIdx.x], x[2 * threadIdx.x + 1]));
+        var[threadIdx.x] = sT / Nt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const T m = dev_pairwise_sum<T>(var, F);
+        const T m2 = m / (T)F;
+        st->tol = m2 * (T)st->tol_in;
+        u128 total = 0;
+        for (int r = 0; r < st->world; r++) {
+            st->rank_tot[r] = kc_ulimbs(x[2 * F + 2 * r], x[2 * F + 2 * r + 1]);
+            total += st->rank_tot[r];
+        }
+        st->current_pot = (T)((double)total * (1.0 / 1099511627776.0));
+        st->best = 0;
+    }
+}
+
+// Start of round c: the centre chosen last becomes the PENDING column of the candidate table (its distances are folded
+// into the closest plane by this round's sweep), and the round's L samples are located: owner rank from the ranks'
+// totals, chunk from this rank's prefix table (row `best` of the chunk partials).  sa: what km_kpp_chunkq / km_kpp_sample read.
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_targets(const km_state<T> *__restrict__ st, int c, const unsigned long long *__restrict__ part,
+                                                         double *__restrict__ candT, kpp_sample_args *__restrict__ sa_out)
+{
+    const int F = st->F, L = st->L;
+    double *cc = candT + (size_t)KPP_STRIDE * RSSEG_MAX_FEATURES;
+    for (int i = threadIdx.x; i < KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE; i += KM_THREADS) candT[i] = 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < F) candT[threadIdx.x * KPP_STRIDE + KPP_MAXL] = (double)st->C[c - 1][threadIdx.x];
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int f = 0; f < F; f++) a = fma((double)st->C[c - 1][f], (double)st->C[c - 1][f], a);
+        cc[KPP_MAXL] = a;
+    }
+    __shared__ kpp_sample_args sa;
+    __shared__ u128 ssum[KM_THREADS];
+    __shared__ u128 s_target, s_before;
+    __shared__ int s_owner;
+    for (int i = threadIdx.x; i < (int)(sizeof(sa) / 4); i += KM_THREADS) reinterpret_cast<int *>(&sa)[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sa.with_old = c > 1 ? 1 : 0;
+        sa.offset = st->offset;
+    }
+    const long long nchunks = st->nchunks, n = st->n_local;
+    const unsigned long long *pre = part + (size_t)st->best * nchunks;
+    const long long slice = (nchunks + KM_THREADS - 1) / KM_THREADS;
+    for (int l = 0; l < L; l++) {
+        if (threadIdx.x == 0) {
+            const double r = st->uniforms[(c - 1) * L + l] * (double)st->current_pot;   // uniform(size=L) * current_pot
+            const u128 target = kc_ceil_scaled(r);
+            u128 before = 0;
+            int owner = -1;
+            for (int rk = 0; rk < st->world; rk++) {   // first rank whose inclusive prefix reaches the target
+                if (st->n_all[rk] > 0 && before + st->rank_tot[rk] >= target) { owner = rk; break; }
+                before += st->rank_tot[rk];
+            }
+            s_owner = owner;
+            s_before = before;
+            s_target = target;
+            if (owner < 0 && st->rank == st->last_rank) {   // beyond the total: np.clip(candidate_ids, None, N - 1)
+                sa.mode[l] = 2;
+                sa.c0[l] = 0;
+                sa.direct[l] = n - 1;
+            }
+        }
+        __syncthreads();
+        if (s_owner == st->rank) {
+            u128 mine = 0;
+            const long long c_lo = (long long)threadIdx.x * slice, c_hi = c_lo + slice < nchunks ? c_lo + slice : nchunks;
+            for (long long ch = c_lo; ch < c_hi; ch++) mine += pre[ch];
+            ssum[threadIdx.x] = mine;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u128 run = s_before;
+                const u128 target = s_target;
+                int t = 0;
+                for (; t < KM_THREADS; t++) {
+                    if (run + ssum[t] >= target) break;
+                    run += ssum[t];
+                }
+                long long ch = (long long)t * slice;
+                if (t < KM_THREADS)
+                    for (; ch < nchunks; ch++) {
+                        if (run + pre[ch] >= target) break;
+                        run += pre[ch];
+                    }
+                if (t >= KM_THREADS || ch >= nchunks) ch = nchunks - 1;   // cannot happen: this rank's total reaches the target
+                sa.mode[l] = 1;
+                sa.c0[l] = ch * (long long)km_chunk<T>();
+                const long long left = n - sa.c0[l];
+                sa.cn[l] = left < (long long)km_chunk<T>() ? left : (long long)km_chunk<T>();
+                sa.rem[l] = (unsigned long long)(target - run);   // <= the chunk's own sum: fits 64 bits
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < (int)(sizeof(sa) / 4); i += KM_THREADS) reinterpret_cast<int *>(sa_out)[i] = reinterpret_cast<const int *>(&sa)[i];
+}
+
+// the sampled rows (all ranks now hold them: {global index, F values} per candidate, stride 1 + RSSEG_MAX_FEATURES) become
+// this round's candidate columns
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_cands(km_state<T> *__restrict__ st, const double *__restrict__ xbuf, double *__restrict__ candT)
+{
+    const int F = st->F, L = st->L;
+    double *cc = candT + (size_t)KPP_STRIDE * RSSEG_MAX_FEATURES;
+    for (int i = threadIdx.x; i < L * F; i += KM_THREADS) {
+        const int l = i / F, f = i - l * F;
+        const T v = (T)xbuf[(size_t)l * (1 + RSSEG_MAX_FEATURES) + 1 + f];
+        st->rows[l][f] = v;
+        candT[f * KPP_STRIDE + l] = (double)v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < L) {
+        const int l = threadIdx.x;
+        st->cand_idx[l] = (long long)xbuf[(size_t)l * (1 + RSSEG_MAX_FEATURES)];
+        double a = 0.0;
+        for (int f = 0; f < F; f++) a = fma((double)st->rows[l][f], (double)st->rows[l][f], a);
+        cc[l] = a;
+    }
+}
+
+// potentials of the L candidates from every rank's chunk-sum totals (x: [L][world] limb pairs), the best one wins
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_pick(km_state<T> *__restrict__ st, int c, const long long *__restrict__ x)
+{
+    __shared__ int s_best;
+    const int L = st->L, W = st->world;
+    if (threadIdx.x == 0) {
+        int best = 0;
+        T best_pot = (T)0;
+        for (int l = 0; l < L; l++) {
+            u128 tot = 0;
+            for (int r = 0; r < W; r++) tot += kc_ulimbs(x[2 * (l * W + r)], x[2 * (l * W + r) + 1]);
+            const T pt = (T)((double)tot * (1.0 / 1099511627776.0));
+            if (l == 0 || pt < best_pot) { best = l; best_pot = pt; }
+        }
+        st->current_pot = best_pot;
+        st->init_idx[c] = st->cand_idx[best];
+        for (int r = 0; r < W; r++) st->rank_tot[r] = kc_ulimbs(x[2 * (best * W + r)], x[2 * (best * W + r) + 1]);
+        st->best = best;   // its chunk sums are the next prefix table (its min-plane is re-derived by the next round)
+        s_best = best;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < st->F) st->C[c][threadIdx.x] = st->rows[s_best][threadIdx.x];
 }
 
 // ================================================================================================
@@ -1447,7 +1693,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
     const size_t o_samp = carve(sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES));
     const size_t o_qv = carve(sizeof(unsigned long long) * KPP_MAXL * (size_t)CHUNK);
-    const size_t o_red = carve(sizeof(long long) * 2 * M);
+    const size_t o_red = carve(sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * RSSEG_MAX_FEATURES + 2 * RSSEG_MAX_RANKS, (size_t)2 * KPP_MAXL * RSSEG_MAX_RANKS,
+                                                                    (size_t)KPP_MAXL * (1 + RSSEG_MAX_FEATURES)}));
+    const size_t o_sa = carve(sizeof(kpp_sample_args));
     const size_t o_redsave = carve(sizeof(long long) * 2 * M);
     const size_t o_lst = carve(sizeof(lloyd_state<T>));
     const size_t o_mm = carve(sizeof(T) * 2 * (size_t)nblk * F);
@@ -1459,7 +1707,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     RSCHK(ws_reserve(ctx, off));
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F + sizeof(double) * RSSEG_MAX_FEATURES + 64,
                                               sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
-                                              sizeof(long long) * 2 * (size_t)M + sizeof(T) * RSSEG_MAX_CLUSTERS * RSSEG_MAX_FEATURES, (size_t)65536});
+                                              sizeof(long long) * 2 * (size_t)M + sizeof(km_state<T>), (size_t)65536});
     // small host-to-device uploads (candidate rows, centres) go through a ring of pinned slots behind the read-back area:
     // the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came from dies
     // (a slot is reused four uploads later; every k-means++ round and every Lloyd iteration synchronises in between)
@@ -1546,75 +1794,78 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     }
     HIPCHK(ctx, hipMemcpyAsync(d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
 
-    // ---- X.mean(axis=0) and np.var(X, axis=0) with exact sums ----
-    const T Nt = (T)N;
-    // The first k-means++ centre (RandomState.choice over N equal weights: the first draw of the generator) is known as
-    // soon as N is; its row rides on the mean all-reduce: the owner gathers the scaled, NOT yet centred row (the scaler on
-    // the device still has mean 0), every rank adds the bit patterns (zeros elsewhere), the host subtracts the mean in T.
+    // ---- everything from here to the final labels is driven from device-resident state (km_state): the host enqueues
+    // sweeps, small control kernels and (world > 1) stream-ordered all-reduces, and waits only for the Lloyd loop's
+    // convergence flag and for the final read-back ----
     mt19937 rng(seed);
     T C[RSSEG_MAX_CLUSTERS][RSSEG_MAX_FEATURES];
     int64_t init_idx[RSSEG_MAX_CLUSTERS];
+    int last_rank = 0;
+    for (int rk = 0; rk < ctx->world; rk++)
+        if (n_all[rk] > 0) last_rank = rk;
+    // values that cross ranks: in the communication buffer when world > 1 (the hook reduces them in place), else in the workspace
+    const size_t x_need = sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * F, (size_t)2 * F + 2 * (size_t)ctx->world,
+                                                                (size_t)2 * KPP_MAXL * (size_t)ctx->world, (size_t)KPP_MAXL * (1 + RSSEG_MAX_FEATURES)});
+    if (ctx->world > 1 && x_need > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small (%zu > %zu)", x_need, ctx->comm_bytes);
+    long long *d_x = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;
+    auto dev_allreduce = [&](int64_t count, int dtype, int op) -> int {   // stream-ordered: no staging copy, no host synchronisation
+        if (ctx->world <= 1) return RSSEG_OK;
+        const auto t0c = std::chrono::steady_clock::now();
+        const int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
+        if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
+        if (ctx->prof_on) {
+            prof_entry &e = ctx->prof["allreduce"];
+            e.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0c).count();
+            e.launches++;
+        }
+        return RSSEG_OK;
+    };
     {
+        // The first k-means++ centre (RandomState.choice over N equal weights: the first draw of the generator) is known as
+        // soon as N is; the uniform(size=L) draws of the later rounds follow in the generator's order.
+        km_state<T> hs;
+        memset(&hs, 0, sizeof(hs));
         const double u0 = rng.random_sample();
         init_idx[0] = uniform_choice(N, std::is_same<T, float>::value ? RSSEG_F32 : RSSEG_F64, u0);
         if (init_idx[0] >= N) init_idx[0] = N - 1;
+        for (int i = 0; i < (k - 1) * L; i++) hs.uniforms[i] = rng.random_sample();
+        hs.init_idx[0] = init_idx[0];
+        hs.max_iter = max_iter;
+        for (int r = 0; r < ctx->world; r++) hs.n_all[r] = n_all[r];
+        hs.N = N; hs.offset = offset; hs.n_local = n; hs.nchunks = nchunks;
+        hs.rank = ctx->rank; hs.world = ctx->world; hs.k = k; hs.F = F; hs.L = L; hs.last_rank = last_rank;
+        hs.tol_in = tol_in;
+        static_assert(sizeof(hs) <= UP_SLOT, "upload slot too small");
+        HIPCHK(ctx, upload(d_lst, &hs, sizeof(hs)));
     }
-    T row0_raw[RSSEG_MAX_FEATURES];
-    auto mean_pass = [&](i128 *sums) -> int {
+    kpp_sample_args *d_sa = (kpp_sample_args *)(ws + o_sa);
+    // ---- X.mean(axis=0): exact sums; the first centre's row rides on the same all-reduce (the owner gathers the scaled,
+    // NOT yet centred row — the scaler on the device still has mean 0) ----
+    {
         const int64_t li0 = init_idx[0] - offset;
         const bool own0 = li0 >= 0 && li0 < n;
-        const size_t mom_bytes = sizeof(long long) * (size_t)nblk * F;
         if (n > 0) {
             {
                 prof_scope ps(ctx, "moment");
                 hipLaunchKernelGGL((km_moment<T>), dim3(nblk, F), dim3(KM_THREADS), 0, st, pl, n, d_sp, d_mom);
             }
             if (own0) hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li0, d_sp, d_row);
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_mom, mom_bytes, hipMemcpyDeviceToHost, st));
-            if (own0) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + mom_bytes, d_row, sizeof(T) * F, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, rs_sync(ctx));
         }
-        long long lim[3 * RSSEG_MAX_FEATURES];
-        const long long *hp = (const long long *)ctx->h_pin;
-        for (int f = 0; f < F; f++) {
-            i128 s = 0;
-            if (n > 0)
-                for (int b = 0; b < nblk; b++) s += hp[(size_t)f * nblk + b];
-            lim[2 * f] = (long long)(s >> 32);
-            lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
-            double rv = own0 ? (double)((const T *)(ctx->h_pin + mom_bytes))[f] : 0.0;
-            if (rv == 0.0) rv = 0.0;   // -0.0 would not survive the integer sum as a zero
-            memcpy(&lim[2 * F + f], &rv, 8);
-        }
-        RSCHK(comm_allreduce_host(ctx, lim, 3 * F, RSSEG_I64, RSSEG_SUM));
-        for (int f = 0; f < F; f++) {
-            sums[f] = limbs(lim[2 * f], lim[2 * f + 1]);
-            double rv;
-            memcpy(&rv, &lim[2 * F + f], 8);
-            row0_raw[f] = (T)rv;
-        }
-        return RSSEG_OK;
-    };
-    i128 sums[RSSEG_MAX_FEATURES];
-    RSCHK(mean_pass(sums));
-    for (int f = 0; f < F; f++) {
-        volatile T s = fixed_to_T<T>(sums[f]);
-        volatile T m = s / Nt;
-        sp.mean[f] = m;
+        hipLaunchKernelGGL((kc_mean_pack<T>), dim3(1), dim3(KM_THREADS), 0, st, (const km_state<T> *)d_lst, (const long long *)d_mom, nblk, (const T *)d_row,
+                           own0 ? 1 : 0, d_x);
+        HIPCHK(ctx, hipGetLastError());
+        RSCHK(dev_allreduce(3 * F, RSSEG_I64, RSSEG_SUM));
+        hipLaunchKernelGGL((kc_mean_apply<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, d_sp, (const long long *)d_x, d_cand);
+        HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
-    T tol = (T)0;  // mean(np.var(X, axis=0)) * tol: the variance sums ride on the first k-means++ pass below
-    if (info) {
+    if (info)
         for (int f = 0; f < F; f++) {
             info->scale[f] = (double)sp.scale[f];
             info->min[f] = (double)sp.minv[f];
-            info->mean[f] = (double)sp.mean[f];
         }
-    }
 
     // ---- k-means++ (_kmeans.py:213-270) ----
-    // fetch scaled+centred rows of global pixel indices; every rank ends up with all rows
+    // fetch scaled+centred rows of global pixel indices; every rank ends up with all rows (empty-cluster relocation only)
     auto fetch_rows = [&](const int64_t *gidx, int cnt, T rows[][RSSEG_MAX_FEATURES]) -> int {
         double buf[KPP_MAXL * RSSEG_MAX_FEATURES];
         memset(buf, 0, sizeof(buf));
@@ -1633,203 +1884,53 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             for (int f = 0; f < F; f++) rows[l][f] = (T)buf[l * F + f];
         return RSSEG_OK;
     };
-    // candidate rows (columns 0..cnt-1) and the pending centre (column KPP_MAXL; may be null) as float64, transposed
-    auto upload_cands = [&](T rows[][RSSEG_MAX_FEATURES], int cnt, const T *pending) -> int {
-        double flat[KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE];  // [F][KPP_STRIDE] rows, then the KPP_STRIDE squared norms
-        double *cc = flat + KPP_STRIDE * RSSEG_MAX_FEATURES;
-        memset(flat, 0, sizeof(flat));
-        auto put = [&](const T *row, int col) {
-            double a = 0.0;
-            for (int f = 0; f < F; f++) {
-                flat[f * KPP_STRIDE + col] = (double)row[f];
-                a = std::fma((double)row[f], (double)row[f], a);
-            }
-            cc[col] = a;
-        };
-        for (int l = 0; l < cnt; l++) put(rows[l], l);
-        if (pending) put(pending, KPP_MAXL);
-        static_assert(sizeof(flat) <= UP_SLOT, "upload slot too small");
-        HIPCHK(ctx, upload(d_cand, flat, sizeof(flat)));  // one copy: rows + norms
-        return RSSEG_OK;
-    };
-    // per-rank totals of the local chunk partials (row `row` of d_part), and the local prefix table
-    std::vector<unsigned long long> h_part((size_t)nchunks * (size_t)std::max(KPP_MAXL, F + 1));
-    auto pull_partials = [&](int rows) -> int {
+    // first sweep: the potential of the first centre per chunk (row 0) and the np.var numerators (rows 1..F)
+    if (n > 0) {
+        prof_scope ps(ctx, "kpp");
+        launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, 0, d_closest, (unsigned long long *)d_part);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    {   // np.var(X, axis=0) and every rank's total of row 0 in ONE all-reduce: x = [F limb pairs][world limb pairs]
+        HIPCHK(ctx, hipMemsetAsync(d_x, 0, sizeof(long long) * (2 * (size_t)F + 2 * (size_t)ctx->world), st));
         if (n > 0) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * (size_t)rows * nchunks, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, rs_sync(ctx));
-            memcpy(h_part.data(), ctx->h_pin, sizeof(long long) * (size_t)rows * nchunks);
-        } else {
-            std::fill(h_part.begin(), h_part.end(), 0ull);
-        }
-        return RSSEG_OK;
-    };
-
-    {
-        T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
-        for (int f = 0; f < F; f++) {   // the centring the device applies: fl(fl(fl(x * scale) + min) - mean)
-            volatile T v = row0_raw[f] - sp.mean[f];
-            rows[0][f] = v;
-        }
-        for (int f = 0; f < F; f++) C[0][f] = rows[0][f];
-        RSCHK(upload_cands(rows, 1, nullptr));
-        if (n > 0) {
-            prof_scope ps(ctx, "kpp");
-            launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, 1, 0, d_closest, (unsigned long long *)d_part);
+            hipLaunchKernelGGL(km_reduce_cols, dim3(F), dim3(KM_THREADS), 0, st, (const long long *)d_part + nchunks, nchunks, d_x, (const int *)nullptr, 1, 0);
+            hipLaunchKernelGGL(km_reduce_cols, dim3(1), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_x + 2 * F, (const int *)nullptr, 1, ctx->rank);
         }
         HIPCHK(ctx, hipGetLastError());
+        RSCHK(dev_allreduce(2 * F + 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
+        hipLaunchKernelGGL((kc_tol<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, (const long long *)d_x);
+        HIPCHK(ctx, hipGetLastError());
     }
-    RSCHK(pull_partials(1 + F));
-    u128 rank_tot[RSSEG_MAX_RANKS], total = 0;
-    {   // np.var(X, axis=0) from rows 1..F of the partials, and every rank's total of row 0 (the potential of the first
-        // centre), in ONE all-reduce
-        long long lim[2 * RSSEG_MAX_FEATURES + 2 * RSSEG_MAX_RANKS];
-        memset(lim, 0, sizeof(lim));
-        for (int f = 0; f < F; f++) {
-            i128 s = 0;
-            if (n > 0)
-                for (int64_t c = 0; c < nchunks; c++) s += (long long)h_part[(size_t)(1 + f) * nchunks + c];
-            lim[2 * f] = (long long)(s >> 32);
-            lim[2 * f + 1] = (long long)(s & 0xffffffffLL);
-        }
-        u128 loc = 0;
-        if (n > 0)
-            for (int64_t c = 0; c < nchunks; c++) loc += h_part[c];
-        lim[2 * F + 2 * ctx->rank] = (long long)(loc >> 32);
-        lim[2 * F + 2 * ctx->rank + 1] = (long long)(loc & 0xffffffffull);
-        RSCHK(comm_allreduce_host(ctx, lim, 2 * F + 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
-        T var[RSSEG_MAX_FEATURES];
-        for (int f = 0; f < F; f++) {
-            volatile T s = fixed_to_T<T>(limbs(lim[2 * f], lim[2 * f + 1]));
-            volatile T v = s / Nt;
-            var[f] = v;
-        }
-        volatile T m = np_pairwise_sum<T>(var, F);
-        volatile T m2 = m / (T)F;
-        volatile T t = m2 * (T)tol_in;
-        tol = t;
-        if (info) info->tol = (double)tol;
-        for (int r = 0; r < ctx->world; r++) {
-            rank_tot[r] = ((u128)(unsigned long long)lim[2 * F + 2 * r] << 32) + (u128)(unsigned long long)lim[2 * F + 2 * r + 1];
-            total += rank_tot[r];
-        }
-    }
-    T current_pot = (T)((double)total * (1.0 / 1099511627776.0));
-    std::vector<unsigned long long> prefix_part((size_t)nchunks);  // this rank's closest-dist chunk sums
-    for (int64_t c = 0; c < nchunks; c++) prefix_part[c] = h_part[c];
-
     for (int c = 1; c < k; c++) {
-        // centre c-1 is pending: its distances are folded into the closest plane by this round's pass, and by
+        // centre c-1 is pending: its distances are folded into the closest plane by this round's sweep, and by
         // km_kpp_chunkq for the chunks the samples fall into
-        RSCHK(upload_cands(nullptr, 0, C[c - 1]));
-        int64_t cand_idx[KPP_MAXL];
+        hipLaunchKernelGGL((kc_targets<T>), dim3(1), dim3(KM_THREADS), 0, st, (const km_state<T> *)d_lst, c, (const unsigned long long *)d_part, d_cand, d_sa);
         // xbuf[l] = {global pixel index, its F scaled+centred values}: filled by the rank that owns the pixel, zeros
         // elsewhere, so ONE sum all-reduce hands every rank both the sampled indices and the candidate rows
-        double xbuf[KPP_MAXL * (1 + RSSEG_MAX_FEATURES)];
-        memset(xbuf, 0, sizeof(xbuf));
-        int last_rank = 0;
-        for (int rk = 0; rk < ctx->world; rk++)
-            if (n_all[rk] > 0) last_rank = rk;
-        kpp_sample_args sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.with_old = c > 1 ? 1 : 0;
-        sa.offset = offset;
-        int mine = 0;
-        for (int l = 0; l < L; l++) {
-            const double r = rng.random_sample() * (double)current_pot;  // uniform(size=L) * current_pot
-            const long double rl = ceill((long double)r * 1099511627776.0L);
-            const u128 target = rl <= 0 ? (u128)0 : (u128)rl;
-            // owner rank: first rank whose inclusive prefix reaches the target
-            u128 before = 0;
-            int owner = -1;
-            for (int rk = 0; rk < ctx->world; rk++) {
-                if (n_all[rk] > 0 && before + rank_tot[rk] >= target) { owner = rk; break; }
-                before += rank_tot[rk];
-            }
-            if (owner < 0) {  // beyond the total: np.clip(candidate_ids, None, N-1) -> the last pixel of the last stripe
-                if (ctx->rank != last_rank) continue;
-                sa.mode[l] = 2;
-                sa.c0[l] = 0;
-                sa.direct[l] = n - 1;
-            } else {
-                if (owner != ctx->rank) continue;
-                u128 run = before;
-                int64_t ch = 0;
-                for (; ch < nchunks; ch++) {
-                    if (run + prefix_part[ch] >= target) break;
-                    run += prefix_part[ch];
-                }
-                if (ch >= nchunks) ch = nchunks - 1;  // cannot happen: rank total reaches the target
-                sa.mode[l] = 1;
-                sa.c0[l] = ch * CHUNK;
-                sa.cn[l] = std::min<int64_t>(CHUNK, n - sa.c0[l]);
-                sa.rem[l] = (unsigned long long)(target - run);  // <= the chunk's own sum: fits 64 bits
-            }
-            mine++;
-        }
-        if (mine > 0) {  // one launch locates the pixels inside their chunks and gathers their rows; one copy back
+        double *d_xbuf = (double *)d_x;
+        HIPCHK(ctx, hipMemsetAsync(d_xbuf, 0, sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES), st));
+        if (n > 0) {
             hipLaunchKernelGGL((km_kpp_chunkq<T>), dim3((unsigned)(CHUNK / KM_THREADS), L), dim3(KM_THREADS), 0, st, pl, F, d_sp, d_cand, d_cc,
-                               (const T *)d_closest, sa, d_qv);
-            hipLaunchKernelGGL((km_kpp_sample<T>), dim3(L), dim3(KM_THREADS), 0, st, pl, F, d_sp, (const unsigned long long *)d_qv, sa, d_samp);
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_samp, sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, rs_sync(ctx));
-            const double *hs = (const double *)ctx->h_pin;
-            for (int l = 0; l < L; l++)
-                if (sa.mode[l] != 0)
-                    for (int f = 0; f <= F; f++) xbuf[(size_t)l * (1 + F) + f] = hs[(size_t)l * (1 + RSSEG_MAX_FEATURES) + f];
+                               (const T *)d_closest, (const kpp_sample_args *)d_sa, d_qv);
+            hipLaunchKernelGGL((km_kpp_sample<T>), dim3(L), dim3(KM_THREADS), 0, st, pl, F, d_sp, (const unsigned long long *)d_qv, (const kpp_sample_args *)d_sa, d_xbuf);
         }
-        RSCHK(comm_allreduce_host(ctx, xbuf, (int64_t)L * (1 + F), RSSEG_F64, RSSEG_SUM));
-        T rows[KPP_MAXL][RSSEG_MAX_FEATURES];
-        for (int l = 0; l < L; l++) {
-            cand_idx[l] = (int64_t)xbuf[(size_t)l * (1 + F)];
-            for (int f = 0; f < F; f++) rows[l][f] = (T)xbuf[(size_t)l * (1 + F) + 1 + f];
-        }
-        RSCHK(upload_cands(rows, L, C[c - 1]));
+        HIPCHK(ctx, hipGetLastError());
+        RSCHK(dev_allreduce((int64_t)L * (1 + RSSEG_MAX_FEATURES), RSSEG_F64, RSSEG_SUM));
+        hipLaunchKernelGGL((kc_cands<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, (const double *)d_xbuf, d_cand);
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
             launch_kpp<T>(ctx, nchunks, pl, F, n, d_sp, d_cand, d_cc, L, c > 1 ? 2 : 1, d_closest, (unsigned long long *)d_part);
         }
         HIPCHK(ctx, hipGetLastError());
-        RSCHK(pull_partials(L));
         // potentials of all L candidates with ONE all-reduce: slot [l][rank] = this rank's chunk-sum total
-        u128 rt_all[KPP_MAXL][RSSEG_MAX_RANKS], tot_all[KPP_MAXL];
-        {
-            long long lim[2 * KPP_MAXL * RSSEG_MAX_RANKS];   // per call: contexts of several threads run this function concurrently
-            memset(lim, 0, sizeof(lim));
-            for (int l = 0; l < L; l++) {
-                u128 loc = 0;
-                if (n > 0)
-                    for (int64_t c2 = 0; c2 < nchunks; c2++) loc += h_part[(size_t)l * nchunks + c2];
-                lim[2 * (l * ctx->world + ctx->rank)] = (long long)(loc >> 32);
-                lim[2 * (l * ctx->world + ctx->rank) + 1] = (long long)(loc & 0xffffffffull);
-            }
-            RSCHK(comm_allreduce_host(ctx, lim, 2 * (int64_t)L * ctx->world, RSSEG_I64, RSSEG_SUM));
-            for (int l = 0; l < L; l++) {
-                tot_all[l] = 0;
-                for (int r = 0; r < ctx->world; r++) {
-                    rt_all[l][r] = ((u128)(unsigned long long)lim[2 * (l * ctx->world + r)] << 32) + (u128)(unsigned long long)lim[2 * (l * ctx->world + r) + 1];
-                    tot_all[l] += rt_all[l][r];
-                }
-            }
-        }
-        int best = 0;
-        T best_pot = (T)0;
-        for (int l = 0; l < L; l++) {
-            T pt = (T)((double)tot_all[l] * (1.0 / 1099511627776.0));
-            if (l == 0 || pt < best_pot) { best = l; best_pot = pt; }
-        }
-        current_pot = best_pot;
-        for (int f = 0; f < F; f++) C[c][f] = rows[best][f];
-        init_idx[c] = cand_idx[best];
-        // the best candidate's chunk sums become the prefix table (its min-plane is re-derived by the next round)
-        for (int r = 0; r < ctx->world; r++) rank_tot[r] = rt_all[best][r];
-        total = tot_all[best];
-        for (int64_t cc2 = 0; cc2 < nchunks; cc2++) prefix_part[cc2] = h_part[(size_t)best * nchunks + cc2];
+        HIPCHK(ctx, hipMemsetAsync(d_x, 0, sizeof(long long) * 2 * (size_t)L * (size_t)ctx->world, st));
+        if (n > 0) hipLaunchKernelGGL(km_reduce_cols, dim3(L), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_x, (const int *)nullptr, ctx->world, ctx->rank);
+        RSCHK(dev_allreduce(2 * (int64_t)L * ctx->world, RSSEG_I64, RSSEG_SUM));
+        hipLaunchKernelGGL((kc_pick<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, c, (const long long *)d_x);
+        HIPCHK(ctx, hipGetLastError());
     }
-    if (info)
-        for (int j = 0; j < k; j++) info->init_indices[j] = init_idx[j];
     const double t_init = now_ms();
+    T tol = (T)0;   // known on the host only after the state has come back (empty-cluster path, info)
 
     // ---- Lloyd (_kmeans_single_lloyd) ----
     // accumulator copies: 32 when they fit in ~48 KB (3 workgroups per CU), fewer for large k * F
@@ -2010,22 +2111,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     // ---- device-resident loop: batches of speculatively enqueued iterations, one look at the state per batch ----
     long long *d_sums = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;   // where km_reduce_cols leaves the limb sums
     if (ctx->world > 1 && sizeof(long long) * 2 * (size_t)M > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small");
-    {
-        lloyd_state<T> h_st;
-        memset(&h_st, 0, sizeof(h_st));
-        memcpy(h_st.C, C, sizeof(C));
-        h_st.tol = tol;
-        h_st.max_iter = max_iter;
-        static_assert(sizeof(h_st) <= UP_SLOT, "upload slot too small");
-        HIPCHK(ctx, upload(d_lst, &h_st, sizeof(h_st)));
-    }
     bool finished = false, host_mode = false;
     int batch = 4;
     while (!finished && !host_mode) {
         const int todo = std::min(batch, max_iter - it);
         for (int b = 0; b < todo; b++) {
             RSCHK(run_lloyd(true, true, false));
-            hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_sums, (const int *)&d_lst->done);
+            hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_sums, (const int *)&d_lst->done, 1, 0);
             HIPCHK(ctx, hipGetLastError());
             if (ctx->world > 1) {   // stream-ordered: no staging copy, no host synchronisation (include/rsseg.h, rsseg_allreduce_fn)
                 const auto t0c = std::chrono::steady_clock::now();
@@ -2058,12 +2150,21 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         }
         batch = 8;
     }
-    if (host_mode || finished) {   // the centres the device loop ended with (the host continues from them, or reports them)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lst->C, sizeof(C), hipMemcpyDeviceToHost, st));
-        if (host_mode) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + sizeof(C), d_redsave, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
+    km_state<T> *h_state = (km_state<T> *)ctx->h_pin;
+    {   // the state the device loop ended with: centres, tolerance, means, seeds (the host reports them, or continues from them)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lst, sizeof(km_state<T>), hipMemcpyDeviceToHost, st));
+        if (host_mode) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + sizeof(km_state<T>), d_redsave, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, rs_sync(ctx));
-        memcpy(C, ctx->h_pin, sizeof(C));
-        if (host_mode) memcpy(red.data(), ctx->h_pin + sizeof(C), sizeof(long long) * 2 * M);
+        memcpy(C, h_state->C, sizeof(C));
+        tol = h_state->tol;
+        for (int f = 0; f < F; f++) sp.mean[f] = h_state->mean[f];
+        for (int j = 0; j < k; j++) init_idx[j] = h_state->init_idx[j];
+        if (host_mode) memcpy(red.data(), ctx->h_pin + sizeof(km_state<T>), sizeof(long long) * 2 * M);
+        if (info) {
+            info->tol = (double)tol;
+            for (int f = 0; f < F; f++) info->mean[f] = (double)sp.mean[f];
+            for (int j = 0; j < k; j++) info->init_indices[j] = init_idx[j];
+        }
     }
     if (host_mode) {
         // the iteration in which a cluster ran empty: its E-step and its (all-reduced) sums exist, the centres the kernels
@@ -2073,7 +2174,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         while (!end) {
             RSCHK(run_lloyd(true, false, true));
             if (n > 0) {
-                hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_red, (const int *)nullptr);
+                hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_red, (const int *)nullptr, 1, 0);
                 HIPCHK(ctx, hipGetLastError());
                 HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_red, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
                 HIPCHK(ctx, rs_sync(ctx));
