@@ -229,7 +229,7 @@ extern "C" int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const
     }
     HIPCHK(ctx, hipGetLastError());
     RSCHK(mm_end(ctx, 7));
-    return stream_sync(ctx);
+    return ctx->mm_collect ? RSSEG_OK : stream_sync(ctx);   // the extrema read-back has already waited for the stream
 }
 
 extern "C" int rsseg_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, float mult, uint8_t *d_q)

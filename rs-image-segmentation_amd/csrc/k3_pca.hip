@@ -509,5 +509,5 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
         HIPCHK(ctx, hipGetLastError());
         RSCHK(mm_end(ctx, n_components));
     }
-    return stream_sync(ctx);
+    return ctx->mm_collect ? RSSEG_OK : stream_sync(ctx);   // the extrema read-back has already waited for the stream
 }

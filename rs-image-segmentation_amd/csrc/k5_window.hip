@@ -698,7 +698,7 @@ static int resize_rows(rsseg_ctx *ctx, const float *const *d_src, int nplanes, i
     }
     HIPCHK(ctx, hipGetLastError());
     RSCHK(mm_end(ctx, nplanes));
-    return stream_sync(ctx);
+    return ctx->mm_collect ? RSSEG_OK : stream_sync(ctx);   // the extrema read-back has already waited for the stream
 }
 
 extern "C" int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw)

@@ -405,14 +405,20 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_sample(planes_t pl, int F, 
     const int64_t c0 = a.c0[l], cn = a.cn[l];
     if (a.mode[l] == 1) {
         const unsigned long long *q = qv + (size_t)l * km_chunk<T>();
-        for (int r = threadIdx.x; r < ROWS; r += KM_THREADS) rowsum[r] = 0ull;
-        __syncthreads();
-#pragma unroll 8
-        for (int r = 0; r < ROWS; r++) {
-            const int64_t i = (int64_t)r * KM_THREADS + threadIdx.x;
-            unsigned long long v = i < cn ? q[i] : 0ull;
+        const int wv = threadIdx.x >> 6, ln = lane_id();
+        static_assert(ROWS % 4 == 0, "rows are dealt to the four waves");
+        // row sums: wave w takes rows w, w + 4, ...; a lane's loads are independent and issued together
+#pragma unroll
+        for (int rr = 0; rr < ROWS / 4; rr++) {
+            const int r = rr * 4 + wv;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t i = (int64_t)r * KM_THREADS + j * 64 + ln;
+                v += i < cn ? q[i] : 0ull;
+            }
             v = wave_sum(v);
-            if (lane_id() == 0 && v) atomicAdd(&rowsum[r], v);
+            if (ln == 0) rowsum[r] = v;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -424,24 +430,26 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_sample(planes_t pl, int F, 
             }
             s_row = r;                 // ROWS: never reached (cannot happen: the chunk sum reaches the target)
             s_rem = a.rem[l] - run;    // what the pixels of row r still have to cover
+            s_li = cn - 1;             // np.clip: nothing reaches the target (cannot happen) -> the chunk's last pixel
         }
         __syncthreads();
-        if (s_row >= ROWS) {
-            if (threadIdx.x == 0) s_li = cn - 1;
-        } else {
+        if (s_row < ROWS) {
+            // first pixel of the row whose inclusive running sum reaches s_rem: wave-level scans + the waves' totals
             const int64_t i = (int64_t)s_row * KM_THREADS + threadIdx.x;
-            rowq[threadIdx.x] = i < cn ? q[i] : 0ull;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned long long run = 0;
-                int64_t li = cn - 1;
-                for (int t = 0; t < KM_THREADS; t++) {
-                    if ((int64_t)s_row * KM_THREADS + t >= cn) break;
-                    run += rowq[t];
-                    if (run >= s_rem) { li = (int64_t)s_row * KM_THREADS + t; break; }
-                }
-                s_li = li;
+            const unsigned long long v = i < cn ? q[i] : 0ull;
+            unsigned long long pfx = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long t = __shfl_up(pfx, o, 64);
+                if (ln >= o) pfx += t;
             }
+            if (ln == 63) rowq[wv] = pfx;
+            __syncthreads();
+            unsigned long long base = 0;
+            for (int w2 = 0; w2 < wv; w2++) base += rowq[w2];
+            const bool hit = i < cn && base + pfx >= s_rem;
+            const unsigned long long m = __ballot(hit);
+            if (m && ln == (int)__builtin_ctzll(m)) atomicMin((unsigned long long *)&s_li, (unsigned long long)i);
         }
         __syncthreads();
     } else {
@@ -1019,8 +1027,17 @@ __global__ __launch_bounds__(KM_THREADS) void km_reduce_cols(const long long *__
     if (done && *done) return;
     const int m = blockIdx.x;
     long long hi = 0, lo = 0;
-    for (int64_t c = threadIdx.x; c < nchunks; c += KM_THREADS) {
-        long long v = partial[(size_t)m * nchunks + c];
+    const long long *row = partial + (size_t)m * nchunks;
+    int64_t c = threadIdx.x;
+    for (; c + 7 * KM_THREADS < nchunks; c += 8 * KM_THREADS) {   // eight loads in flight per thread
+        long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = row[c + u * KM_THREADS];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { hi += v[u] >> 32; lo += v[u] & 0xffffffffLL; }
+    }
+    for (; c < nchunks; c += KM_THREADS) {
+        const long long v = row[c];
         hi += v >> 32;
         lo += v & 0xffffffffLL;
     }
@@ -1078,13 +1095,9 @@ template <typename T> __device__ __forceinline__ T t_sqrt(T x);
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return __fsqrt_rn(x); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return __dsqrt_rn(x); }
 
-// cenT[f * KMAX + j] = C[j][f] (zeros elsewhere), csq[j] = fma chain of C[j][f]^2 over f — row_norms(centers, squared=True)
-template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void kl_prepare(const lloyd_state<T> *__restrict__ st, int k, int F, int KMAX, T *__restrict__ cenT,
-                                                         int force)
+// cenT / csq of the centres in the state, as kl_prepare writes them (all threads of the workgroup)
+template <typename T> __device__ __forceinline__ void kl_fill_cenT(const km_state<T> *st, int k, int F, int KMAX, T *__restrict__ cenT)
 {
-    if (st->done && !force) return;
-    T *csq = cenT + (size_t)KMAX * RSSEG_MAX_FEATURES;
     for (int i = threadIdx.x; i < KMAX * RSSEG_MAX_FEATURES + KMAX; i += KM_THREADS) {
         T v = (T)0;
         if (i < KMAX * RSSEG_MAX_FEATURES) {
@@ -1097,6 +1110,15 @@ __global__ __launch_bounds__(KM_THREADS) void kl_prepare(const lloyd_state<T> *_
         }
         cenT[i] = v;
     }
+}
+
+// cenT[f * KMAX + j] = C[j][f] (zeros elsewhere), csq[j] = fma chain of C[j][f]^2 over f — row_norms(centers, squared=True)
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kl_prepare(const lloyd_state<T> *__restrict__ st, int k, int F, int KMAX, T *__restrict__ cenT,
+                                                         int force)
+{
+    if (st->done && !force) return;
+    kl_fill_cenT<T>(st, k, F, KMAX, cenT);
 }
 
 __device__ __forceinline__ i128 dev_limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
@@ -1121,13 +1143,14 @@ template <typename T> __device__ T dev_pairwise_sum(const T *a, int n)   // nump
 
 // red: [M][2] limb sums of this iteration over all ranks (km_reduce_cols, all-reduced), M = KMAX * F + KMAX + 1
 template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *__restrict__ st, int k, int F, int KMAX, const long long *__restrict__ red,
-                                                        long long *__restrict__ red_saved)
+__global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *st, int k, int F, int KMAX, const long long *__restrict__ red,
+                                                        long long *__restrict__ red_saved, T *__restrict__ cenT)
 {
     if (st->done) return;
     __shared__ long long cnt[RSSEG_MAX_CLUSTERS];
     __shared__ T shift2[RSSEG_MAX_CLUSTERS];
-    __shared__ int n_empty;
+    __shared__ int n_empty, s_done;
+    __shared__ __align__(16) char kl_scratch[sizeof(T) * RSSEG_MAX_CLUSTERS * RSSEG_MAX_FEATURES];
     const int M = KMAX * F + KMAX + 1;
     if (threadIdx.x == 0) n_empty = 0;
     __syncthreads();
@@ -1143,37 +1166,32 @@ __global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *__restri
         if (threadIdx.x == 0) st->done = 3;
         return;
     }
-    // _average_centers, then _center_shift per cluster (one thread per cluster walks its F columns in the host's order)
-    if ((int)threadIdx.x < k) {
-        const int j = threadIdx.x;
+    // _average_centers for all (cluster, feature) pairs in parallel, then _center_shift per cluster (one thread per cluster
+    // adds the squared differences in the host's order: groups of four, then the remainder)
+    T *dsq = reinterpret_cast<T *>(kl_scratch);   // [k][F] squared differences
+    for (int i = threadIdx.x; i < k * F; i += KM_THREADS) {
+        const int j = i / F, f = i - j * F;
         const T w = (T)cnt[j];
         const T alpha = (T)(1.0 / (double)w);
+        const T sT = dev_fixed_to_T<T>(dev_limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]));
+        const T cnew = sT * alpha;
+        const T d = cnew - st->C[j][f];
+        dsq[i] = d * d;
+        st->C[j][f] = cnew;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < k) {
+        const int j = threadIdx.x;
+        const T *t = dsq + j * F;
         T result = (T)0;
         const int n4 = F / 4, rem = F % 4;
-        int f = 0;
-        T cn[4];
-        for (int g = 0; g < n4; g++, f += 4) {
-            T d[4];
-            for (int u = 0; u < 4; u++) {
-                const T sT = dev_fixed_to_T<T>(dev_limbs(red[2 * (j * F + f + u)], red[2 * (j * F + f + u) + 1]));
-                cn[u] = sT * alpha;
-                d[u] = cn[u] - st->C[j][f + u];
-            }
-            const T t0 = d[0] * d[0], t1 = d[1] * d[1], t2 = d[2] * d[2], t3 = d[3] * d[3];
-            const T g1 = t0 + t1;
-            const T g2 = g1 + t2;
-            const T g4 = g2 + t3;
+        for (int g = 0; g < n4; g++, t += 4) {
+            const T g1 = t[0] + t[1];
+            const T g2 = g1 + t[2];
+            const T g4 = g2 + t[3];
             result = result + g4;
-            for (int u = 0; u < 4; u++) st->C[j][f + u] = cn[u];
         }
-        for (int r = 0; r < rem; r++, f++) {
-            const T sT = dev_fixed_to_T<T>(dev_limbs(red[2 * (j * F + f)], red[2 * (j * F + f) + 1]));
-            const T c1 = sT * alpha;
-            const T d = c1 - st->C[j][f];
-            const T t = d * d;
-            result = result + t;
-            st->C[j][f] = c1;
-        }
+        for (int r = 0; r < rem; r++) result = result + t[r];
         const T sh = t_sqrt<T>(result);
         shift2[j] = sh * sh;
     }
@@ -1190,7 +1208,10 @@ __global__ __launch_bounds__(KM_THREADS) void kl_update(lloyd_state<T> *__restri
             else if (it >= st->max_iter) done = 4;
         }
         st->done = done;
+        s_done = done;
     }
+    __syncthreads();
+    if (!s_done) kl_fill_cenT<T>(st, k, F, KMAX, cenT);   // the next E-step's centres (a converged loop keeps the last E-step's)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1218,18 +1239,14 @@ __device__ __forceinline__ u128 kc_ceil_scaled(double r)
 }
 __device__ __forceinline__ u128 kc_ulimbs(long long hi, long long lo) { return ((u128)(unsigned long long)hi << 32) + (u128)(unsigned long long)lo; }
 
-// per-feature sums of the scaled matrix from km_moment's block partials, and the (not yet centred) row of the first centre
+// the (not yet centred) row of the first centre as bit patterns behind the F limb pairs of the column sums (which
+// km_reduce_cols leaves in x[0 .. 2F) from km_moment's block partials)
 template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void kc_mean_pack(const km_state<T> *__restrict__ st, const long long *__restrict__ mom, int nblk,
-                                                           const T *__restrict__ row, int own0, long long *__restrict__ x)
+__global__ __launch_bounds__(64) void kc_mean_pack(const km_state<T> *__restrict__ st, const T *__restrict__ row, int own0, long long *__restrict__ x)
 {
     const int F = st->F, f = threadIdx.x;
     if (f >= F) return;
-    i128 s = 0;
-    if (st->n_local > 0)
-        for (int b = 0; b < nblk; b++) s += mom[(size_t)f * nblk + b];
-    x[2 * f] = (long long)(s >> 32);
-    x[2 * f + 1] = (long long)(s & 0xffffffffLL);
+    if (st->n_local <= 0) { x[2 * f] = 0; x[2 * f + 1] = 0; }
     double rv = own0 ? (double)row[f] : 0.0;
     if (rv == 0.0) rv = 0.0;   // -0.0 would not survive the integer sum as a zero
     x[2 * F + f] = __double_as_longlong(rv);
@@ -1293,10 +1310,18 @@ __global__ __launch_bounds__(KM_THREADS) void kc_tol(km_state<T> *__restrict__ s
 // Start of round c: the centre chosen last becomes the PENDING column of the candidate table (its distances are folded
 // into the closest plane by this round's sweep), and the round's L samples are located: owner rank from the ranks'
 // totals, chunk from this rank's prefix table (row `best` of the chunk partials).  sa: what km_kpp_chunkq / km_kpp_sample read.
+template <typename T> __device__ __forceinline__ void kc_pick_body(km_state<T> *st, int c, const long long *x);
+
+// pick_c > 0: first close round pick_c (kc_pick) with the potentials in `lim`.  Then both exchange regions are cleared
+// for this round: xbuf (the sampled rows, filled by their owner) and lim (the potentials, filled per rank).
 template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void kc_targets(const km_state<T> *__restrict__ st, int c, const unsigned long long *__restrict__ part,
-                                                         double *__restrict__ candT, kpp_sample_args *__restrict__ sa_out)
+__global__ __launch_bounds__(KM_THREADS) void kc_targets(km_state<T> *st, int c, int pick_c, const unsigned long long *__restrict__ part,
+                                                         double *__restrict__ candT, kpp_sample_args *__restrict__ sa_out, double *xbuf, long long *lim)
 {
+    if (pick_c > 0) kc_pick_body<T>(st, pick_c, lim);
+    for (int i = threadIdx.x; i < KPP_MAXL * (1 + RSSEG_MAX_FEATURES); i += KM_THREADS) xbuf[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * KPP_MAXL * RSSEG_MAX_RANKS; i += KM_THREADS)
+        if (i < 2 * st->L * st->world) lim[i] = 0;
     const int F = st->F, L = st->L;
     double *cc = candT + (size_t)KPP_STRIDE * RSSEG_MAX_FEATURES;
     for (int i = threadIdx.x; i < KPP_STRIDE * RSSEG_MAX_FEATURES + KPP_STRIDE; i += KM_THREADS) candT[i] = 0.0;
@@ -1308,20 +1333,42 @@ __global__ __launch_bounds__(KM_THREADS) void kc_targets(const km_state<T> *__re
         cc[KPP_MAXL] = a;
     }
     __shared__ kpp_sample_args sa;
-    __shared__ u128 ssum[KM_THREADS];
-    __shared__ u128 s_target, s_before;
-    __shared__ int s_owner;
+    __shared__ u128 ssum[KM_THREADS];   // sums of KM_THREADS contiguous slices of this rank's prefix table
+    __shared__ u128 gsum[16];           // sums of 16 groups of 16 slices
     for (int i = threadIdx.x; i < (int)(sizeof(sa) / 4); i += KM_THREADS) reinterpret_cast<int *>(&sa)[i] = 0;
+    const long long nchunks = st->nchunks, n = st->n_local;
+    const unsigned long long *pre = part + (size_t)st->best * nchunks;
+    const long long slice = (nchunks + KM_THREADS - 1) / KM_THREADS;
+    {
+        u128 mine = 0;
+        const long long c_lo = (long long)threadIdx.x * slice, c_hi = c_lo + slice < nchunks ? c_lo + slice : nchunks;
+        if (n > 0) {
+            long long ch = c_lo;
+            for (; ch + 8 <= c_hi; ch += 8) {   // eight loads in flight
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = pre[ch + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) mine += v[u];
+            }
+            for (; ch < c_hi; ch++) mine += pre[ch];
+        }
+        ssum[threadIdx.x] = mine;
+    }
     __syncthreads();
+    if (threadIdx.x < 16) {
+        u128 g = 0;
+        for (int t = 0; t < 16; t++) g += ssum[threadIdx.x * 16 + t];
+        gsum[threadIdx.x] = g;
+    }
     if (threadIdx.x == 0) {
         sa.with_old = c > 1 ? 1 : 0;
         sa.offset = st->offset;
     }
-    const long long nchunks = st->nchunks, n = st->n_local;
-    const unsigned long long *pre = part + (size_t)st->best * nchunks;
-    const long long slice = (nchunks + KM_THREADS - 1) / KM_THREADS;
-    for (int l = 0; l < L; l++) {
-        if (threadIdx.x == 0) {
+    __syncthreads();
+    // the L samples are independent: lane 0 of wave w locates candidates w, w + 4, ...
+    if ((threadIdx.x & 63) == 0) {
+        for (int l = threadIdx.x >> 6; l < L; l += KM_THREADS / 64) {
             const double r = st->uniforms[(c - 1) * L + l] * (double)st->current_pot;   // uniform(size=L) * current_pot
             const u128 target = kc_ceil_scaled(r);
             u128 before = 0;
@@ -1330,46 +1377,42 @@ __global__ __launch_bounds__(KM_THREADS) void kc_targets(const km_state<T> *__re
                 if (st->n_all[rk] > 0 && before + st->rank_tot[rk] >= target) { owner = rk; break; }
                 before += st->rank_tot[rk];
             }
-            s_owner = owner;
-            s_before = before;
-            s_target = target;
-            if (owner < 0 && st->rank == st->last_rank) {   // beyond the total: np.clip(candidate_ids, None, N - 1)
-                sa.mode[l] = 2;
-                sa.c0[l] = 0;
-                sa.direct[l] = n - 1;
+            if (owner < 0) {                           // beyond the total: np.clip(candidate_ids, None, N - 1)
+                if (st->rank == st->last_rank) {
+                    sa.mode[l] = 2;
+                    sa.c0[l] = 0;
+                    sa.direct[l] = n - 1;
+                }
+                continue;
             }
-        }
-        __syncthreads();
-        if (s_owner == st->rank) {
-            u128 mine = 0;
-            const long long c_lo = (long long)threadIdx.x * slice, c_hi = c_lo + slice < nchunks ? c_lo + slice : nchunks;
-            for (long long ch = c_lo; ch < c_hi; ch++) mine += pre[ch];
-            ssum[threadIdx.x] = mine;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u128 run = s_before;
-                const u128 target = s_target;
-                int t = 0;
-                for (; t < KM_THREADS; t++) {
+            if (owner != st->rank) continue;
+            u128 run = before;
+            int g = 0;
+            for (; g < 16; g++) {
+                if (run + gsum[g] >= target) break;
+                run += gsum[g];
+            }
+            int t = g * 16;
+            if (g < 16)
+                for (; t < g * 16 + 16; t++) {
                     if (run + ssum[t] >= target) break;
                     run += ssum[t];
                 }
-                long long ch = (long long)t * slice;
-                if (t < KM_THREADS)
-                    for (; ch < nchunks; ch++) {
-                        if (run + pre[ch] >= target) break;
-                        run += pre[ch];
-                    }
-                if (t >= KM_THREADS || ch >= nchunks) ch = nchunks - 1;   // cannot happen: this rank's total reaches the target
-                sa.mode[l] = 1;
-                sa.c0[l] = ch * (long long)km_chunk<T>();
-                const long long left = n - sa.c0[l];
-                sa.cn[l] = left < (long long)km_chunk<T>() ? left : (long long)km_chunk<T>();
-                sa.rem[l] = (unsigned long long)(target - run);   // <= the chunk's own sum: fits 64 bits
-            }
+            long long ch = (long long)t * slice;
+            if (g < 16 && t < g * 16 + 16)
+                for (; ch < nchunks; ch++) {
+                    if (run + pre[ch] >= target) break;
+                    run += pre[ch];
+                }
+            if (ch >= nchunks) ch = nchunks - 1;   // cannot happen: this rank's total reaches the target
+            sa.mode[l] = 1;
+            sa.c0[l] = ch * (long long)km_chunk<T>();
+            const long long left = n - sa.c0[l];
+            sa.cn[l] = left < (long long)km_chunk<T>() ? left : (long long)km_chunk<T>();
+            sa.rem[l] = (unsigned long long)(target - run);   // <= the chunk's own sum: fits 64 bits
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int i = threadIdx.x; i < (int)(sizeof(sa) / 4); i += KM_THREADS) reinterpret_cast<int *>(sa_out)[i] = reinterpret_cast<const int *>(&sa)[i];
 }
 
@@ -1397,8 +1440,7 @@ __global__ __launch_bounds__(KM_THREADS) void kc_cands(km_state<T> *__restrict__
 }
 
 // potentials of the L candidates from every rank's chunk-sum totals (x: [L][world] limb pairs), the best one wins
-template <typename T>
-__global__ __launch_bounds__(KM_THREADS) void kc_pick(km_state<T> *__restrict__ st, int c, const long long *__restrict__ x)
+template <typename T> __device__ __forceinline__ void kc_pick_body(km_state<T> *st, int c, const long long *x)
 {
     __shared__ int s_best;
     const int L = st->L, W = st->world;
@@ -1419,6 +1461,13 @@ __global__ __launch_bounds__(KM_THREADS) void kc_pick(km_state<T> *__restrict__ 
     }
     __syncthreads();
     if ((int)threadIdx.x < st->F) st->C[c][threadIdx.x] = st->rows[s_best][threadIdx.x];
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(KM_THREADS) void kc_pick(km_state<T> *st, int c, const long long *x)
+{
+    kc_pick_body<T>(st, c, x);
 }
 
 // ================================================================================================
@@ -1693,8 +1742,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t o_row = carve(sizeof(T) * RSSEG_MAX_FEATURES);
     const size_t o_samp = carve(sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES));
     const size_t o_qv = carve(sizeof(unsigned long long) * KPP_MAXL * (size_t)CHUNK);
-    const size_t o_red = carve(sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * RSSEG_MAX_FEATURES + 2 * RSSEG_MAX_RANKS, (size_t)2 * KPP_MAXL * RSSEG_MAX_RANKS,
-                                                                    (size_t)KPP_MAXL * (1 + RSSEG_MAX_FEATURES)}));
+    const size_t o_red = carve(sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * RSSEG_MAX_FEATURES + 2 * RSSEG_MAX_RANKS,
+                                                                    (size_t)2 * KPP_MAXL * RSSEG_MAX_RANKS + KPP_MAXL * (1 + RSSEG_MAX_FEATURES) + 64}));
     const size_t o_sa = carve(sizeof(kpp_sample_args));
     const size_t o_redsave = carve(sizeof(long long) * 2 * M);
     const size_t o_lst = carve(sizeof(lloyd_state<T>));
@@ -1805,13 +1854,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         if (n_all[rk] > 0) last_rank = rk;
     // values that cross ranks: in the communication buffer when world > 1 (the hook reduces them in place), else in the workspace
     const size_t x_need = sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * F, (size_t)2 * F + 2 * (size_t)ctx->world,
-                                                                (size_t)2 * KPP_MAXL * (size_t)ctx->world, (size_t)KPP_MAXL * (1 + RSSEG_MAX_FEATURES)});
+                                                                (size_t)2 * KPP_MAXL * RSSEG_MAX_RANKS + KPP_MAXL * (1 + RSSEG_MAX_FEATURES) + 64});
     if (ctx->world > 1 && x_need > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small (%zu > %zu)", x_need, ctx->comm_bytes);
     long long *d_x = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;
-    auto dev_allreduce = [&](int64_t count, int dtype, int op) -> int {   // stream-ordered: no staging copy, no host synchronisation
+    auto dev_allreduce = [&](int64_t byte_off, int64_t count, int dtype, int op) -> int {   // stream-ordered: no staging copy, no host synchronisation
         if (ctx->world <= 1) return RSSEG_OK;
         const auto t0c = std::chrono::steady_clock::now();
-        const int rc = ctx->allreduce(ctx->comm_user, 0, count, dtype, op);
+        const int rc = ctx->allreduce(ctx->comm_user, byte_off, count, dtype, op);
         if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
         if (ctx->prof_on) {
             prof_entry &e = ctx->prof["allreduce"];
@@ -1851,10 +1900,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             }
             if (own0) hipLaunchKernelGGL((km_gather_row<T>), dim3(1), dim3(64), 0, st, pl, F, li0, d_sp, d_row);
         }
-        hipLaunchKernelGGL((kc_mean_pack<T>), dim3(1), dim3(KM_THREADS), 0, st, (const km_state<T> *)d_lst, (const long long *)d_mom, nblk, (const T *)d_row,
-                           own0 ? 1 : 0, d_x);
+        if (n > 0) hipLaunchKernelGGL(km_reduce_cols, dim3(F), dim3(KM_THREADS), 0, st, (const long long *)d_mom, (int64_t)nblk, d_x, (const int *)nullptr, 1, 0);
+        hipLaunchKernelGGL((kc_mean_pack<T>), dim3(1), dim3(64), 0, st, (const km_state<T> *)d_lst, (const T *)d_row, own0 ? 1 : 0, d_x);
         HIPCHK(ctx, hipGetLastError());
-        RSCHK(dev_allreduce(3 * F, RSSEG_I64, RSSEG_SUM));
+        RSCHK(dev_allreduce(0, 3 * F, RSSEG_I64, RSSEG_SUM));
         hipLaunchKernelGGL((kc_mean_apply<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, d_sp, (const long long *)d_x, d_cand);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -1897,25 +1946,28 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             hipLaunchKernelGGL(km_reduce_cols, dim3(1), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_x + 2 * F, (const int *)nullptr, 1, ctx->rank);
         }
         HIPCHK(ctx, hipGetLastError());
-        RSCHK(dev_allreduce(2 * F + 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
+        RSCHK(dev_allreduce(0, 2 * F + 2 * ctx->world, RSSEG_I64, RSSEG_SUM));
         hipLaunchKernelGGL((kc_tol<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, (const long long *)d_x);
         HIPCHK(ctx, hipGetLastError());
     }
+    // exchange regions of a round inside x: the sampled rows at byte 0, the candidates' potentials behind them
+    constexpr size_t LIM_OFF = ((sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES)) + 511) & ~(size_t)511;
+    double *d_xbuf = (double *)d_x;
+    long long *d_lim = (long long *)((char *)d_x + LIM_OFF);
     for (int c = 1; c < k; c++) {
         // centre c-1 is pending: its distances are folded into the closest plane by this round's sweep, and by
-        // km_kpp_chunkq for the chunks the samples fall into
-        hipLaunchKernelGGL((kc_targets<T>), dim3(1), dim3(KM_THREADS), 0, st, (const km_state<T> *)d_lst, c, (const unsigned long long *)d_part, d_cand, d_sa);
+        // km_kpp_chunkq for the chunks the samples fall into.  (The previous round's choice is made at the head of this kernel.)
+        hipLaunchKernelGGL((kc_targets<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, c, c > 1 ? c - 1 : 0, (const unsigned long long *)d_part, d_cand, d_sa,
+                           d_xbuf, d_lim);
         // xbuf[l] = {global pixel index, its F scaled+centred values}: filled by the rank that owns the pixel, zeros
         // elsewhere, so ONE sum all-reduce hands every rank both the sampled indices and the candidate rows
-        double *d_xbuf = (double *)d_x;
-        HIPCHK(ctx, hipMemsetAsync(d_xbuf, 0, sizeof(double) * KPP_MAXL * (1 + RSSEG_MAX_FEATURES), st));
         if (n > 0) {
             hipLaunchKernelGGL((km_kpp_chunkq<T>), dim3((unsigned)(CHUNK / KM_THREADS), L), dim3(KM_THREADS), 0, st, pl, F, d_sp, d_cand, d_cc,
                                (const T *)d_closest, (const kpp_sample_args *)d_sa, d_qv);
             hipLaunchKernelGGL((km_kpp_sample<T>), dim3(L), dim3(KM_THREADS), 0, st, pl, F, d_sp, (const unsigned long long *)d_qv, (const kpp_sample_args *)d_sa, d_xbuf);
         }
         HIPCHK(ctx, hipGetLastError());
-        RSCHK(dev_allreduce((int64_t)L * (1 + RSSEG_MAX_FEATURES), RSSEG_F64, RSSEG_SUM));
+        RSCHK(dev_allreduce(0, (int64_t)L * (1 + RSSEG_MAX_FEATURES), RSSEG_F64, RSSEG_SUM));
         hipLaunchKernelGGL((kc_cands<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, (const double *)d_xbuf, d_cand);
         if (n > 0) {
             prof_scope ps(ctx, "kpp");
@@ -1923,10 +1975,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         }
         HIPCHK(ctx, hipGetLastError());
         // potentials of all L candidates with ONE all-reduce: slot [l][rank] = this rank's chunk-sum total
-        HIPCHK(ctx, hipMemsetAsync(d_x, 0, sizeof(long long) * 2 * (size_t)L * (size_t)ctx->world, st));
-        if (n > 0) hipLaunchKernelGGL(km_reduce_cols, dim3(L), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_x, (const int *)nullptr, ctx->world, ctx->rank);
-        RSCHK(dev_allreduce(2 * (int64_t)L * ctx->world, RSSEG_I64, RSSEG_SUM));
-        hipLaunchKernelGGL((kc_pick<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, c, (const long long *)d_x);
+        if (n > 0) hipLaunchKernelGGL(km_reduce_cols, dim3(L), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_lim, (const int *)nullptr, ctx->world, ctx->rank);
+        RSCHK(dev_allreduce((int64_t)LIM_OFF, 2 * (int64_t)L * ctx->world, RSSEG_I64, RSSEG_SUM));
+    }
+    if (k > 1) {
+        hipLaunchKernelGGL((kc_pick<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, k - 1, (const long long *)d_lim);
         HIPCHK(ctx, hipGetLastError());
     }
     const double t_init = now_ms();
@@ -1942,8 +1995,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     // their transposed copy and norms; `done`-guarded unless forced); otherwise from the host array C.
     auto run_lloyd = [&](bool update, bool from_state, bool force) -> int {
         if (from_state) {
-            hipLaunchKernelGGL((kl_prepare<T>), dim3(1), dim3(KM_THREADS), 0, st, (const lloyd_state<T> *)d_lst, k, F, KMAX, d_cen, force ? 1 : 0);
-            HIPCHK(ctx, hipGetLastError());
+            // d_cen already holds the transposed centres of the state: kl_prepare before the first iteration, kl_update after each
         } else {
             // upload centres (transposed) and their squared norms (fma chain in T, row_norms of centres)
             T cenT[RSSEG_MAX_FEATURES * RSSEG_MAX_CLUSTERS + RSSEG_MAX_CLUSTERS];  // [MAX_FEATURES][KMAX] centres, then KMAX norms
@@ -2113,6 +2165,9 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     if (ctx->world > 1 && sizeof(long long) * 2 * (size_t)M > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small");
     bool finished = false, host_mode = false;
     int batch = 4;
+    km_state<T> *h_state = (km_state<T> *)ctx->h_pin;
+    hipLaunchKernelGGL((kl_prepare<T>), dim3(1), dim3(KM_THREADS), 0, st, (const lloyd_state<T> *)d_lst, k, F, KMAX, d_cen, 1);
+    HIPCHK(ctx, hipGetLastError());
     while (!finished && !host_mode) {
         const int todo = std::min(batch, max_iter - it);
         for (int b = 0; b < todo; b++) {
@@ -2130,14 +2185,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                     e.launches++;
                 }
             }
-            hipLaunchKernelGGL((kl_update<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, k, F, KMAX, (const long long *)d_sums, d_redsave);
+            hipLaunchKernelGGL((kl_update<T>), dim3(1), dim3(KM_THREADS), 0, st, d_lst, k, F, KMAX, (const long long *)d_sums, d_redsave, d_cen);
             HIPCHK(ctx, hipGetLastError());
         }
-        // one look at the state
-        int *hflags = (int *)ctx->h_pin;
-        HIPCHK(ctx, hipMemcpyAsync(hflags, &d_lst->it, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        // one look at the state (all of it: when the loop has ended, the centres, tolerance, means and seeds are here already)
+        HIPCHK(ctx, hipMemcpyAsync(h_state, d_lst, sizeof(km_state<T>), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, rs_sync(ctx));
-        const int it_new = hflags[0], done = hflags[1];
+        const int it_new = h_state->it, done = h_state->done;
         prof_retag(ctx, "lloyd", todo - (it_new - it) - (done == 3 ? 1 : 0), "lloyd_noop");   // launches that returned at once
         it = it_new;
         if (done == 1 || done == 2 || done == 4) {
@@ -2148,13 +2202,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         } else if (it >= max_iter) {
             finished = true;
         }
-        batch = 8;
+        batch = std::max(2, it / 3);   // short fits are not over-enqueued, long ones are looked at ever more rarely
     }
-    km_state<T> *h_state = (km_state<T> *)ctx->h_pin;
     {   // the state the device loop ended with: centres, tolerance, means, seeds (the host reports them, or continues from them)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_lst, sizeof(km_state<T>), hipMemcpyDeviceToHost, st));
-        if (host_mode) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + sizeof(km_state<T>), d_redsave, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, rs_sync(ctx));
+        if (host_mode) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin + sizeof(km_state<T>), d_redsave, sizeof(long long) * 2 * M, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, rs_sync(ctx));
+        }
         memcpy(C, h_state->C, sizeof(C));
         tol = h_state->tol;
         for (int f = 0; f < F; f++) sp.mean[f] = h_state->mean[f];

@@ -195,10 +195,17 @@ def _with_minmax(fn):
     @functools.wraps(fn)
     def wrapped(ctx, *args, **kwargs):
         ctx.collect_minmax(True)
+        # entry points whose results stay on the device do not wait for the stream (rsseg_ctx_set_async): the calls that
+        # hand values to the host (order statistics, extrema, PCA sums) wait by themselves, and KMeans ends with a wait
+        was_async = getattr(ctx, "_async", False)
+        if not was_async:
+            ctx.set_async(True)
         try:
             return fn(ctx, *args, **kwargs)
         finally:
             ctx.collect_minmax(False)
+            if not was_async:
+                ctx.end_async()
     return wrapped
 
 

@@ -143,6 +143,16 @@ class Context:
         self._chk(self.lib.rsseg_ctx_sync(self.h))
         self._keep = []
 
+    def end_async(self):
+        """Back to synchronous entry points.  The buffers kept alive for queued kernels are released to torch's caching
+        allocator, which recycles them in stream order: safe when this context's stream is the stream they were allocated
+        on (torch's current stream, the default); a context on a side stream (aux()) must use sync() instead."""
+        self._chk(self.lib.rsseg_ctx_set_async(self.h, 0))
+        self._async = False
+        if self.torch_stream != _torch().cuda.current_stream(self.device):
+            self._chk(self.lib.rsseg_ctx_sync(self.h))
+        self._keep = []
+
     def aux(self):
         """A second context on its own HIP stream (same device, asynchronous entry points): lets a
         VALU-bound kernel run beside the HBM-bound passes issued through this context."""
