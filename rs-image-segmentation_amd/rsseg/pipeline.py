@@ -46,31 +46,31 @@ def band_quantile_bundles(ctx: Context, bands: Sequence, n_global: Optional[int]
     qr, qf = percentile_plan(n, (25.0, 75.0), np.float32, False)
     ranks = p2r + p98r + mr + qr
     out: List[dict] = []
+    cuts = np.cumsum([0, len(p2r), len(p98r), len(mr), len(qr)])
     for g0 in range(0, len(bands), 8):
         group = list(bands[g0:g0 + 8])
         vals_all, nan_all = ctx.order_stats_multi(group, [ranks] * len(group))
-        for band, vals, n_nan in zip(group, vals_all, nan_all):
+        # the host arithmetic of all planes of the group at once (elementwise NumPy operations on (P,) arrays give, value
+        # for value, what the same operations give on one plane's scalars): the GPU idles while this runs
+        parts = [vals_all[:, cuts[i]:cuts[i + 1]] for i in range(4)]
+        lo, hi = p2f(parts[0]), p98f(parts[1])            # (P,) float32
+        den = hi - lo + 1e-10                            # float32, as in robust_normalize
+
+        def f(v):
+            return (np.clip(v, lo[:, None], hi[:, None]) - lo[:, None]) / den[:, None]
+
+        with np.errstate(invalid="ignore"):
+            center = mf(f(parts[2])).astype(np.float32)
+            q = qf(f(parts[3]))                          # (P, 2) float64
+            scale = (q[:, 1] - q[:, 0]).astype(np.float64)
+            scale = np.where(scale < 10 * np.finfo(np.float64).eps, np.float64(1.0), scale)
+            lo2, hi2 = p2f(f(parts[0])), p98f(f(parts[1]))
+        for i, (band, n_nan) in enumerate(zip(group, nan_all)):
             if n_nan > 0:
-                lo, hi = band_percentiles(ctx, band, (2, 98), n_global)
-                out.append(dict(lo=lo, hi=hi, center=None, scale=None, lo2=None, hi2=None))
-                continue
-            o = 0
-            parts = []
-            for r in (p2r, p98r, mr, qr):
-                parts.append(vals[o:o + len(r)])
-                o += len(r)
-            lo, hi = p2f(parts[0]), p98f(parts[1])
-            den = hi - lo + 1e-10  # float32, as in robust_normalize
-
-            def f(v, lo=lo, hi=hi, den=den):
-                return (np.clip(v, lo, hi) - lo) / den
-
-            center = np.float32(mf(f(parts[2])))
-            q = qf(f(parts[3]))
-            scale = np.float64(q[1] - q[0])
-            if scale < 10 * np.finfo(np.float64).eps:
-                scale = np.float64(1.0)
-            out.append(dict(lo=lo, hi=hi, center=center, scale=scale, lo2=p2f(f(parts[0])), hi2=p98f(f(parts[1]))))
+                blo, bhi = band_percentiles(ctx, band, (2, 98), n_global)
+                out.append(dict(lo=blo, hi=bhi, center=None, scale=None, lo2=None, hi2=None))
+            else:
+                out.append(dict(lo=lo[i], hi=hi[i], center=center[i], scale=scale[i], lo2=lo2[i], hi2=hi2[i]))
     return out
 
 

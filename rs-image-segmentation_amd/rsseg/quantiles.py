@@ -7,6 +7,7 @@ rounding follow NumPy 2.x exactly.
 """
 from __future__ import annotations
 
+import functools
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -44,6 +45,7 @@ def _lerp(a, b, t):
     return out
 
 
+@functools.lru_cache(maxsize=256)   # a plan depends on (n, q) only; a step asks for the same few again and again
 def percentile_plan(n: int, q, a_dtype=np.float32, scalar_q: bool = True):
     """Returns (ranks, finish): `ranks` are the 0-based order statistics to fetch; finish(values) maps
     the fetched values (same order, a_dtype) to the percentile value(s)."""
@@ -55,6 +57,19 @@ def percentile_plan(n: int, q, a_dtype=np.float32, scalar_q: bool = True):
 
     def finish(values: np.ndarray):
         v = np.asarray(values, dtype=a_dtype)
+        if v.ndim == 2:
+            # several planes at once, one row of fetched values each: the same elementwise operations on (P,) / (P, m)
+            # arrays as on the scalars of one plane (rows holding a NaN come back as NaN)
+            P = v.shape[0]
+            prev_v = v[:, :m].reshape((P,) + np.shape(gamma))
+            next_v = v[:, m:].reshape((P,) + np.shape(gamma))
+            with np.errstate(invalid="ignore"):
+                res = np.asarray(_lerp(prev_v, next_v, gamma))
+            bad = np.isnan(v).any(axis=1)
+            if bad.any():
+                res = res.copy()
+                res[bad] = np.nan
+            return res
         if np.isnan(v).any():
             res = np.full(np.shape(gamma), np.nan, dtype=np.result_type(a_dtype, gamma.dtype))
             return res[()] if res.ndim == 0 else res
@@ -66,6 +81,7 @@ def percentile_plan(n: int, q, a_dtype=np.float32, scalar_q: bool = True):
     return ranks, finish
 
 
+@functools.lru_cache(maxsize=256)
 def median_plan(n: int, a_dtype=np.float32):
     """np.median / np.nanmedian of n valid values: mean of the middle one or two order statistics in
     the array dtype (numpy _median: mean(part[indexer]))."""
@@ -76,7 +92,7 @@ def median_plan(n: int, a_dtype=np.float32):
 
     def finish(values: np.ndarray):
         v = np.asarray(values, dtype=a_dtype)
-        return np.mean(v)
+        return np.mean(v, axis=1) if v.ndim == 2 else np.mean(v)   # rows = planes
 
     return ranks, finish
 
