@@ -1,0 +1,68 @@
+"""Simulation (CPU, test infrastructure: uses the oracle) for VERDICT r02 item 4: an exact incremental Lloyd update would skip a
+pixel only when a conservative bound PROVES that its label cannot change: stored slack G(x) = d(x, 2nd nearest centre) -
+d(x, nearest centre) at its last evaluation against the cumulative drift 2 * sum(max_j |c_j(t+1) - c_j(t)|) since then.
+On the reference's bundled scene (600 x 600, the 7 spectral indices, k = 6 / 8: 47 / 51 iterations) this prints, per
+iteration, the fraction of pixels and of 32-pixel groups (one 128-byte line of a float32 plane: the granularity at which
+skipping saves HBM traffic) that must be re-evaluated, the fraction that really changes, and the check that no skipped
+pixel ever changes (viol = 0).   python3 profiles/lloyd_skip_sim.py > profiles/r03_lloyd_skip_sim.txt"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rs-image-segmentation_amd"))
+import numpy as np
+from oracle import ref_np as O
+
+def features_scene():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "scene_aa.npz"))
+    bands = O.stage1_preprocess(g['dn'])
+    norm = [O.robust_normalize(b) for b in bands]
+    b, gr, r, n, s = norm[:5]
+    return [O.calculate_ndvi(n, r), O.calculate_evi(n, r, b), O.calculate_msavi(n, r), O.calculate_ndwi(gr, n), O.calculate_mndwi(gr, s), O.calculate_ndbi(s, n), O.calculate_bsi(b, r, n, s)]
+
+def sim(planes, k, W, group=32, maxit=300):
+    X = np.stack([p.reshape(-1) for p in planes], 1).astype(np.float64)
+    X = np.nan_to_num(X)
+    mn, mx = X.min(0), X.max(0)
+    X = (X - mn) / np.where(mx > mn, mx - mn, 1)
+    X -= X.mean(0)
+    n, F = X.shape
+    tol = 1e-4 * X.var(0).mean()
+    lab0, info = O.kmeans_fit_planes(planes, k)
+    # init: use the oracle's seeds
+    C = X[info['init_indices']].copy()
+    T = np.full(n, -np.inf)
+    Dcum = 0.0
+    lab = np.full(n, -1)
+    rows = []
+    for it in range(maxit):
+        need = T <= Dcum + 3e-4          # margin m(t)
+        # group granularity
+        ng = n // group
+        gneed = need[:ng * group].reshape(ng, group).any(1)
+        # evaluate everything (truth) to verify and to get statistics
+        d2 = ((X[:, None, :] - C[None]) ** 2).sum(2)
+        newlab = d2.argmin(1)
+        viol = int(((newlab != lab) & ~need).sum()) if it else 0
+        e = np.sqrt(np.sort(d2, 1)[:, :2])
+        G = e[:, 1] - e[:, 0]
+        T = np.where(need, G + Dcum, T)
+        changed = int((newlab != lab).sum())
+        gch = (newlab != lab)[:ng * group].reshape(ng, group).any(1).mean()
+        lab = newlab
+        Cn = np.stack([X[lab == j].mean(0) if (lab == j).any() else C[j] for j in range(k)])
+        delta = np.sqrt(((Cn - C) ** 2).sum(1))
+        shift = (delta ** 2).sum()
+        rows.append((it, need.mean(), gneed.mean(), changed / n, gch, delta.max(), viol))
+        Dcum += 2 * delta.max()
+        C = Cn
+        if changed == 0 or shift <= tol:
+            break
+    return rows, info['n_iter']
+
+if __name__ == '__main__':
+    planes = features_scene()
+    for k in (6, 8):
+        rows, nit = sim(planes, k, 600)
+        print(f"k={k} oracle n_iter={nit}, sim iters={len(rows)}")
+        tot = 0
+        for r in rows:
+            print("it %2d need_px %.4f need_grp32 %.4f changed %.5f chg_grp %.4f dmax %.2e viol %d" % r)
+        g = np.array([r[2] for r in rows]); print("mean need_grp32 over iterations: %.3f ; bytes/px model: %.1f vs 62" % (g.mean(), 4 + g.mean() * 66))

@@ -160,6 +160,45 @@ __global__ __launch_bounds__(1024) void k_lds_chain(unsigned long long *t, unsig
     if (acc == 0x12345) sink[0] = acc;
 }
 
+// ---- (c) the same chain with 4-BYTE nodes and integer features: what a rank-quantised forest would walk (VERDICT r02 item 6:
+// thresholds replaced by their rank among the forest's thresholds of that feature, a pixel's features by their ranks, so that
+// a node fits 32 bits: {rank : 12, feature : 4, next : 16} here) — one ds_read_b32 + one dependent ds_read_b32 per step ----
+template <int NCH>
+__global__ __launch_bounds__(1024) void k_lds_chain32(unsigned long long *t, unsigned *sink, int nodes, int steps)
+{
+    extern __shared__ __align__(16) char smem[];
+    unsigned *feat = (unsigned *)smem;                           // [16][1024] ranks
+    unsigned *tab = feat + 16 * 1024;                            // nodes
+    for (int j = threadIdx.x; j < 16 * 1024; j += blockDim.x) feat[j] = ((j * 2654435761u) >> 20) & 0xfffu;
+    for (int j = threadIdx.x; j < nodes; j += blockDim.x) {
+        const unsigned h = (j * 2246822519u) ^ 0x9e3779b9u;
+        tab[j] = (((h >> 7) % (nodes - 1)) & 0xffffu) | ((h & 15u) << 16) | (0x800u << 20);
+    }
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned lu;
+    const unsigned fbase = (unsigned)(uintptr_t)(lu *)feat + threadIdx.x * 4u, tbase = (unsigned)(uintptr_t)(lu *)tab;
+    unsigned nd[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) nd[q] = tab[(threadIdx.x * 7 + q * 131) % nodes];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < steps; s++) {
+        unsigned x[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; q++) x[q] = *(lu *)(fbase + ((nd[q] >> 16) & 15u) * 4096u);
+#pragma unroll
+        for (int q = 0; q < NCH; q++) {
+            const unsigned next = (nd[q] & 0xffffu) + (x[q] > (nd[q] >> 20) ? 1u : 0u);
+            nd[q] = *(lu *)(tbase + next * 4u);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) t[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    unsigned acc = 0;
+#pragma unroll
+    for (int q = 0; q < NCH; q++) acc += nd[q];
+    if (acc == 0x12345) sink[0] = acc;
+}
+
 static double median(std::vector<unsigned long long> v)
 {
     std::sort(v.begin(), v.end());
@@ -218,6 +257,30 @@ int main()
                 if (nch == 2) hipLaunchKernelGGL(k_lds_chain<2>, dim3(blocks), dim3(thrs[k]), lds, 0, d_t, d_sink, 8192, steps);
                 if (nch == 4) hipLaunchKernelGGL(k_lds_chain<4>, dim3(blocks), dim3(thrs[k]), lds, 0, d_t, d_sink, 8192, steps);
                 if (nch == 8) hipLaunchKernelGGL(k_lds_chain<8>, dim3(blocks), dim3(thrs[k]), lds, 0, d_t, d_sink, 8192, steps);
+                CHECK(hipDeviceSynchronize());
+            }
+            const int nw = blocks * thrs[k] / 64;
+            CHECK(hipMemcpy(h.data(), d_t, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> v(h.begin(), h.begin() + nw);
+            printf("\"%d_chains\": %.1f%s", nch, median(v) / steps, c < 3 ? ", " : "");
+        }
+        printf("}%s\n", k < 2 ? "," : "");
+    }
+    printf(" },\n \"lds_dependent_chain_b32_nodes\": {\n  \"note\": \"the same round with 4-byte nodes and integer (rank) features: one ds_read_b32 + one dependent ds_read_b32 per chain\",\n");
+    const size_t lds32 = 16 * 1024 * 4 + 8192 * 4;
+    CHECK(hipFuncSetAttribute((const void *)k_lds_chain32<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    CHECK(hipFuncSetAttribute((const void *)k_lds_chain32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    CHECK(hipFuncSetAttribute((const void *)k_lds_chain32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    CHECK(hipFuncSetAttribute((const void *)k_lds_chain32<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    for (int k = 0; k < 3; k++) {
+        printf("  \"%d_waves_per_cu\": {", thrs[k] / 64);
+        for (int c = 0; c < 4; c++) {
+            const int nch = 1 << c;
+            for (int rep = 0; rep < 2; rep++) {
+                if (nch == 1) hipLaunchKernelGGL(k_lds_chain32<1>, dim3(blocks), dim3(thrs[k]), lds32, 0, d_t, d_sink, 8192, steps);
+                if (nch == 2) hipLaunchKernelGGL(k_lds_chain32<2>, dim3(blocks), dim3(thrs[k]), lds32, 0, d_t, d_sink, 8192, steps);
+                if (nch == 4) hipLaunchKernelGGL(k_lds_chain32<4>, dim3(blocks), dim3(thrs[k]), lds32, 0, d_t, d_sink, 8192, steps);
+                if (nch == 8) hipLaunchKernelGGL(k_lds_chain32<8>, dim3(blocks), dim3(thrs[k]), lds32, 0, d_t, d_sink, 8192, steps);
                 CHECK(hipDeviceSynchronize());
             }
             const int nw = blocks * thrs[k] / 64;
