@@ -108,6 +108,12 @@ int rsseg_order_stats_f32(rsseg_ctx *ctx, const float *d_x, int64_t n_local, con
 int rsseg_order_stats_multi_f32(rsseg_ctx *ctx, const float *const *d_planes, int nplanes, int64_t n_local,
                                 const int64_t *ranks, int nranks, float *out_values, int64_t *n_nan_out);
 
+/* The same for 8-bit planes (one byte per pixel; the TM tiles the reference reads are uint8 digital numbers,
+ * modules/features/preprocessing.py:117-118, which scripts/2_feature_extraction.py:156 widens with .astype(np.float32)):
+ * one 256-bin pass, the values come back as float32 like np.percentile of the widened band would give them. */
+int rsseg_order_stats_multi_u8(rsseg_ctx *ctx, const uint8_t *const *d_planes, int nplanes, int64_t n_local,
+                               const int64_t *ranks, int nranks, float *out_values, int64_t *n_nan_out);
+
 /* ---- K2: percentile normalisation + spectral indices ------------------------------------ */
 /* robust_normalize (indices.py:25-48), elementwise part: clip to [lo,hi], (x-lo)/(hi-lo+1e-10)
  * in float32.  d_out may alias d_x. */
@@ -124,6 +130,11 @@ int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_bands, int6
 /* The same with calculate_evi's coefficients evi_coef[4] = {L, C1, C2, G} (indices.py:73; NULL = the defaults 1, 6, 7.5, 2.5). */
 int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
                                    float *const *d_out, float *const *d_norm, const float *evi_coef);
+
+/* The same on 8-bit band planes: bit for bit the result of the float32 entry point on the widened planes (the
+ * normalisation of a byte is a 256-entry table filled with the float path's own operations); 5 B/px read instead of 20. */
+int rsseg_spectral_indices_evi_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int64_t n, const float *lohi,
+                                  float *const *d_out, float *const *d_norm, const float *evi_coef);
 
 /* ---- K3: PCA ------------------------------------------------------------------------------ */
 /* perform_pca (indices.py:205-246): RobustScaler transform x' = (float)((double)(x - center) /
@@ -152,7 +163,12 @@ int rsseg_pca_fit_transform_ext_f32(rsseg_ctx *ctx, const float *const *d_bands,
                                     int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
                                     float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
                                     float *explained_variance);
-/* Errors of the three PCA entry points: RSSEG_ERR_INVALID "Input X contains NaN." / "... infinity" (sklearn's PCA raises
+/* rsseg_pca_fit_transform_ext_f32 on 8-bit band planes (bit for bit the float32 result on the widened planes). */
+int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off,
+                                   int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
+                                   float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
+                                   float *explained_variance);
+/* Errors of the PCA entry points: RSSEG_ERR_INVALID "Input X contains NaN." / "... infinity" (sklearn's PCA raises
  * ValueError on such input, sklearn/utils/validation.py); bands that are not robust-normalised are range-checked
  * with one extra pass so that the exact fixed-point accumulation fits any finite input (raw DN, reflectances). */
 

@@ -162,6 +162,47 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
     }
 }
 
+// 8-bit planes (the TM tiles the reference reads are uint8 digital numbers, preprocessing.py:117-118): bin = value, 256 bins,
+// 16 pixels per 16-byte load.  Every lane adds into one of U8_COPIES private copies of the table (odd word stride: a wave's
+// lanes that carry the same value — coherent image regions — land on different banks).
+#define U8_COPIES 32
+#define U8_STRIDE 257
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k1_hist_u8(const uint8_t *__restrict__ x, int64_t n, unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t lh[U8_COPIES * U8_STRIDE];
+    for (int i = threadIdx.x; i < U8_COPIES * U8_STRIDE; i += THREADS) lh[i] = 0;
+    __syncthreads();
+    uint32_t *mine = lh + (threadIdx.x & (U8_COPIES - 1)) * U8_STRIDE;
+    const int64_t n16 = n >> 4;
+    const uint4 *x16 = reinterpret_cast<const uint4 *>(x);
+    auto word = [&](uint32_t w) {
+        atomicAdd(&mine[w & 255u], 1u);
+        atomicAdd(&mine[(w >> 8) & 255u], 1u);
+        atomicAdd(&mine[(w >> 16) & 255u], 1u);
+        atomicAdd(&mine[w >> 24], 1u);
+    };
+    const int64_t stride = (int64_t)gridDim.x * THREADS;
+    int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    for (; i + stride < n16; i += 2 * stride) {   // two 16-byte loads in flight per lane
+        const uint4 a = x16[i], b = x16[i + stride];
+        word(a.x); word(a.y); word(a.z); word(a.w);
+        word(b.x); word(b.y); word(b.z); word(b.w);
+    }
+    for (; i < n16; i += stride) {
+        const uint4 a = x16[i];
+        word(a.x); word(a.y); word(a.z); word(a.w);
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 15)) atomicAdd(&mine[x[(n16 << 4) + threadIdx.x]], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < 256; b += THREADS) {
+        uint32_t c = 0;
+#pragma unroll 8
+        for (int cp = 0; cp < U8_COPIES; cp++) c += lh[cp * U8_STRIDE + b];
+        if (c) atomicAdd(&hist[b], (unsigned long long)c);
+    }
+}
+
 static float key_to_f32(uint32_t k)
 {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
@@ -354,6 +395,53 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
         for (int r = 0; r < nranks; r++)
             out_values[(size_t)p * nranks + r] = st[p].is_nan_rank[r] ? __builtin_nanf("") : key_to_f32(st[p].prefix[r]);
         if (n_nan_out) n_nan_out[p] = st[p].n_nan;
+    }
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_order_stats_multi_u8(rsseg_ctx *ctx, const uint8_t *const *d_planes, int nplanes, int64_t n_local, const int64_t *ranks,
+                                          int nranks, float *out_values, int64_t *n_nan_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_planes || nplanes < 1 || nplanes > SEL_MAX_PLANES || n_local < 0 || !ranks || !out_values || nranks < 1 || nranks > RSSEG_MAX_RANKS)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats_multi_u8: bad arguments (planes=%d n=%lld nranks=%d)", nplanes, (long long)n_local, nranks);
+    for (int p = 0; p < nplanes; p++)
+        if (!d_planes[p] || ((uintptr_t)d_planes[p] & 15) != 0)
+            return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats_multi_u8: plane %d null or not 16-byte aligned", p);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int P = nplanes;
+    const size_t used = 256;
+    RSCHK(ws_reserve(ctx, (size_t)P * used * 8));
+    RSCHK(pin_reserve(ctx, (size_t)P * used * 8));
+    unsigned long long *d_hist = (unsigned long long *)ctx->d_ws;
+    long long *h_hist = (long long *)ctx->h_pin;
+    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, (size_t)P * used * 8, ctx->stream));
+    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 4, 1024)));
+    for (int p = 0; p < P; p++) {
+        prof_scope ps(ctx, "select");
+        hipLaunchKernelGGL((k1_hist_u8<1024>), dim3(grid), dim3(1024), 0, ctx->stream, d_planes[p], n_local, d_hist + (size_t)p * used);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(h_hist, d_hist, (size_t)P * used * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, rs_sync(ctx));
+    RSCHK(comm_allreduce_host(ctx, h_hist, (int64_t)((size_t)P * used), RSSEG_I64, RSSEG_SUM));
+    for (int p = 0; p < P; p++) {
+        const long long *h = h_hist + (size_t)p * used;
+        const int64_t *rk = ranks + (size_t)p * nranks;
+        int64_t n_global = 0;
+        for (int b = 0; b < 256; b++) n_global += h[b];
+        for (int r = 0; r < nranks; r++) {
+            if (rk[r] < 0 || rk[r] >= n_global)
+                return rs_fail(ctx, RSSEG_ERR_INVALID, "order_stats: rank %lld outside [0,%lld)", (long long)rk[r], (long long)n_global);
+            int64_t acc = 0;
+            int b = 0;
+            for (; b < 256; b++) {
+                if (rk[r] < acc + h[b]) break;
+                acc += h[b];
+            }
+            out_values[(size_t)p * nranks + r] = (float)b;
+        }
+        if (n_nan_out) n_nan_out[p] = 0;
     }
     return RSSEG_OK;
 }

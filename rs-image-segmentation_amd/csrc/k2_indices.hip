@@ -20,7 +20,7 @@ __device__ __forceinline__ float ratio_index(float num, float den)
 }
 
 struct k2_args {
-    const float *band[5];
+    const void *band[5];   // float32 planes, or uint8 planes (k2_indices<.., true>)
     float *out[7];
     float *norm[5];
     float lo[5], hi[5], den[5];
@@ -56,23 +56,45 @@ __device__ __forceinline__ void k2_pixel(const k2_args &a, const float nb[5], fl
 }
 
 // MM: also reduce min / max of the 7 index planes into mm[j] (rsseg_ctx_collect_minmax)
-template <bool MM>
+// U8: the bands are 8-bit planes (1 byte per pixel instead of 4).  A byte has 256 values, so robust_normalize of a band is a
+// 256-entry table — filled by every workgroup with the SAME float32 operations the float path applies per pixel (norm1 of
+// (float)v), hence the same bits — and the 5 IEEE divisions per pixel become 5 LDS look-ups.
+template <bool MM, bool U8>
 __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, uint32_t *__restrict__ mm)
 {
+    __shared__ float lut[U8 ? 5 * 256 : 1];
+    if (U8) {
+        for (int i = threadIdx.x; i < 5 * 256; i += K2_THREADS) {
+            const int j = i >> 8;
+            const float v = (float)(i & 255);
+            lut[i] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
+        }
+        __syncthreads();
+    }
     const int64_t n4 = n >> 2;
     float lmn[7], lmx[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) { lmn[j] = INFINITY; lmx[j] = -INFINITY; }
     for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
-        float4 b[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) b[j] = reinterpret_cast<const float4 *>(a.band[j])[i];
         float nb[4][5], o[4][7];
+        if (U8) {
+            uint32_t w[5];
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const float v[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+            for (int j = 0; j < 5; j++) w[j] = reinterpret_cast<const uint32_t *>(a.band[j])[i];
 #pragma unroll
-            for (int p = 0; p < 4; p++) nb[p][j] = a.normalise ? norm1(v[p], a.lo[j], a.hi[j], a.den[j]) : v[p];
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) nb[p][j] = lut[j * 256 + ((w[j] >> (8 * p)) & 255u)];
+        } else {
+            float4 b[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) b[j] = reinterpret_cast<const float4 *>(a.band[j])[i];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const float v[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) nb[p][j] = a.normalise ? norm1(v[p], a.lo[j], a.hi[j], a.den[j]) : v[p];
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; p++) k2_pixel(a, nb[p], o[p]);
@@ -99,8 +121,11 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
         float nb[5], o[7];
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-            float v = a.band[j][t];
-            nb[j] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
+            if (U8) nb[j] = lut[j * 256 + reinterpret_cast<const uint8_t *>(a.band[j])[t]];
+            else {
+                const float v = reinterpret_cast<const float *>(a.band[j])[t];
+                nb[j] = a.normalise ? norm1(v, a.lo[j], a.hi[j], a.den[j]) : v;
+            }
         }
         k2_pixel(a, nb, o);
         if (MM) {
@@ -193,8 +218,23 @@ extern "C" int rsseg_spectral_indices_f32(rsseg_ctx *ctx, const float *const *d_
     return rsseg_spectral_indices_evi_f32(ctx, d_bands, n, lohi, d_out, d_norm, nullptr);
 }
 
+static int indices_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int64_t n, const float *lohi, float *const *d_out, float *const *d_norm,
+                        const float *evi_coef);
+
 extern "C" int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const *d_bands, int64_t n, const float *lohi,
                                               float *const *d_out, float *const *d_norm, const float *evi_coef)
+{
+    return indices_core(ctx, (const void *const *)d_bands, false, n, lohi, d_out, d_norm, evi_coef);
+}
+
+extern "C" int rsseg_spectral_indices_evi_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int64_t n, const float *lohi,
+                                             float *const *d_out, float *const *d_norm, const float *evi_coef)
+{
+    return indices_core(ctx, (const void *const *)d_bands, true, n, lohi, d_out, d_norm, evi_coef);
+}
+
+static int indices_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int64_t n, const float *lohi, float *const *d_out, float *const *d_norm,
+                        const float *evi_coef)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_bands || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: bad arguments");
@@ -224,8 +264,14 @@ extern "C" int rsseg_spectral_indices_evi_f32(rsseg_ctx *ctx, const float *const
     RSCHK(mm_begin(ctx, 7));
     {
         prof_scope ps(ctx, "indices");
-        if (ctx->mm_collect) hipLaunchKernelGGL(k2_indices<true>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n, ctx->d_mm);
-        else hipLaunchKernelGGL(k2_indices<false>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, a, n, (uint32_t *)nullptr);
+        const dim3 g(stream_grid(n >> 2));
+        if (u8) {
+            if (ctx->mm_collect) hipLaunchKernelGGL((k2_indices<true, true>), g, dim3(K2_THREADS), 0, ctx->stream, a, n, ctx->d_mm);
+            else hipLaunchKernelGGL((k2_indices<false, true>), g, dim3(K2_THREADS), 0, ctx->stream, a, n, (uint32_t *)nullptr);
+        } else {
+            if (ctx->mm_collect) hipLaunchKernelGGL((k2_indices<true, false>), g, dim3(K2_THREADS), 0, ctx->stream, a, n, ctx->d_mm);
+            else hipLaunchKernelGGL((k2_indices<false, false>), g, dim3(K2_THREADS), 0, ctx->stream, a, n, (uint32_t *)nullptr);
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     RSCHK(mm_end(ctx, 7));

@@ -20,7 +20,7 @@
 #define PCA_PSTRIDE (2 * PCA_NACC + 2)  // long longs per block in the partial table of k3_gram
 
 struct pca_args {
-    const float *band[PCA_MAXB];
+    const void *band[PCA_MAXB];   // float32 planes, or uint8 planes (the <.., U8 = true> kernels)
     float center[PCA_MAXB];
     double scale[PCA_MAXB];
     double rinv[PCA_MAXB];  // RN(1 / scale)
@@ -58,9 +58,21 @@ __device__ __forceinline__ long long to_fixed_q(double x, double s)
 // constant bits(1.5*2^52) is subtracted once per thread (count * constant, modulo 2^64) instead of once per term.
 __host__ __device__ constexpr int pca_tri(int b, int c) { return PCA_MAXB + b * PCA_MAXB - b * (b - 1) / 2 + (c - b); }
 
-template <int NB>
+// U8: the bands are 8-bit planes.  pca_x of a band is then a 256-entry table, filled by every workgroup with the operations
+// the float path applies per pixel (same bits): the two divisions per band and pixel become one LDS look-up.
+template <int NB, bool U8> __device__ __forceinline__ void pca_fill_lut(const pca_args &a, float *lut)
+{
+    if (U8) {
+        for (int i = threadIdx.x; i < NB * 256; i += PCA_THREADS) lut[i] = pca_x(a, i >> 8, (float)(i & 255));
+        __syncthreads();
+    }
+}
+
+template <int NB, bool U8>
 __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, long long *__restrict__ partial)
 {
+    __shared__ float lut[U8 ? NB * 256 : 1];
+    pca_fill_lut<NB, U8>(a, lut);
     // partial[blk][2 * PCA_NACC + 2]: the limb sums, then the number of threads that met a NaN (sklearn's PCA rejects
     // NaN input; a NaN's bit pattern in the integer sums would otherwise pass unnoticed), then padding
     bool bad = false;
@@ -69,11 +81,11 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
     for (int i = 0; i < PCA_NACC; i++) acc[i] = 0;
     unsigned long long cnt = 0;
     const int64_t n4 = n >> 2;
-    auto pixel = [&](const float *v) {
+    auto pixel = [&](const float *v) {   // U8: v already holds the table values
         float x[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            x[b] = pca_x(a, b, v[b]);
+            x[b] = U8 ? v[b] : pca_x(a, b, v[b]);
             bad = bad || x[b] != x[b];
         }
 #pragma unroll
@@ -86,19 +98,33 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         cnt++;
     };
     for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
-        float4 v[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
         float p0[NB], p1[NB], p2[NB], p3[NB];
+        if (U8) {
+            uint32_t w[NB];
 #pragma unroll
-        for (int b = 0; b < NB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                p0[b] = lut[b * 256 + (w[b] & 255u)];
+                p1[b] = lut[b * 256 + ((w[b] >> 8) & 255u)];
+                p2[b] = lut[b * 256 + ((w[b] >> 16) & 255u)];
+                p3[b] = lut[b * 256 + (w[b] >> 24)];
+            }
+        } else {
+            float4 v[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+        }
         pixel(p0); pixel(p1); pixel(p2); pixel(p3);
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
     if (t < n) {
         float p[NB];
 #pragma unroll
-        for (int b = 0; b < NB; b++) p[b] = a.band[b][t];
+        for (int b = 0; b < NB; b++)
+            p[b] = U8 ? lut[b * 256 + reinterpret_cast<const uint8_t *>(a.band[b])[t]] : reinterpret_cast<const float *>(a.band[b])[t];
         pixel(p);
     }
     const unsigned long long bias = cnt * (unsigned long long)__double_as_longlong(FX_MAGIC);
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_range(pca_args a, int64_t off,
     for (int b = 0; b < a.nb; b++) {
         float mn = INFINITY, mx = -INFINITY;
         for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCA_THREADS) {
-            const float v = a.band[b][off + i];
+            const float v = reinterpret_cast<const float *>(a.band[b])[off + i];
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
         }
@@ -158,24 +184,36 @@ struct proj_args {
 
 // Specialised on the band count; the component loop stays rolled so that only one component's coefficients are
 // held in scalar registers at a time (with everything unrolled the two argument blocks no longer fit the SGPR file).
-template <int NB, bool MM>
+template <int NB, bool MM, bool U8>
 __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args pr, int64_t n, uint32_t *__restrict__ mm)
 {
+    __shared__ float lut[U8 ? NB * 256 : 1];
+    pca_fill_lut<NB, U8>(a, lut);
     const int64_t n4 = n >> 2;
     float lmn[PCA_MAXB], lmx[PCA_MAXB];  // MM: running extrema per component (indexed by the rolled loop: LDS-free, registers)
 #pragma unroll
     for (int c = 0; c < PCA_MAXB; c++) { lmn[c] = INFINITY; lmx[c] = -INFINITY; }
     for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
-        float4 v[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
         float x[4][NB];
+        if (U8) {
+            uint32_t w[NB];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            x[0][b] = pca_x(a, b, v[b].x);
-            x[1][b] = pca_x(a, b, v[b].y);
-            x[2][b] = pca_x(a, b, v[b].z);
-            x[3][b] = pca_x(a, b, v[b].w);
+            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) x[p][b] = lut[b * 256 + ((w[b] >> (8 * p)) & 255u)];
+        } else {
+            float4 v[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                x[0][b] = pca_x(a, b, v[b].x);
+                x[1][b] = pca_x(a, b, v[b].y);
+                x[2][b] = pca_x(a, b, v[b].z);
+                x[3][b] = pca_x(a, b, v[b].w);
+            }
         }
 #pragma nounroll
         for (int c = 0; c < pr.nc; c++) {
@@ -206,7 +244,8 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
     if (t < n) {
         float x[NB];
 #pragma unroll
-        for (int b = 0; b < NB; b++) x[b] = pca_x(a, b, a.band[b][t]);
+        for (int b = 0; b < NB; b++)
+            x[b] = U8 ? lut[b * 256 + reinterpret_cast<const uint8_t *>(a.band[b])[t]] : pca_x(a, b, reinterpret_cast<const float *>(a.band[b])[t]);
 #pragma nounroll
         for (int c = 0; c < pr.nc; c++) {
             float s = 0.f;
@@ -265,7 +304,7 @@ static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][
     for (int i = 0; i < n; i++) w[i] = A[i][i];
 }
 
-static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
+static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
                     const float *center, const double *scale, int n_components, float *const *d_out, float *components,
                     float *explained_variance_ratio, float *mean, float *explained_variance);
 
@@ -274,7 +313,7 @@ extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d
                                            float *components, float *explained_variance_ratio, float *mean,
                                            float *explained_variance)
 {
-    return pca_core(ctx, d_bands, nb, n_local, 0, n_local, nullptr, center, scale, n_components, d_out, components, explained_variance_ratio,
+    return pca_core(ctx, (const void *const *)d_bands, false, nb, n_local, 0, n_local, nullptr, center, scale, n_components, d_out, components, explained_variance_ratio,
                     mean, explained_variance);
 }
 
@@ -284,7 +323,7 @@ extern "C" int rsseg_pca_fit_transform_raw_f32(rsseg_ctx *ctx, const float *cons
                                                float *explained_variance)
 {
     if (ctx && !lohi) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_raw: lohi is required");
-    return pca_core(ctx, d_bands, nb, n_local, 0, n_local, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
+    return pca_core(ctx, (const void *const *)d_bands, false, nb, n_local, 0, n_local, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
                     mean, explained_variance);
 }
 
@@ -294,14 +333,25 @@ extern "C" int rsseg_pca_fit_transform_ext_f32(rsseg_ctx *ctx, const float *cons
                                                float *explained_variance)
 {
     if (ctx && (fit_off < 0 || fit_n < 0 || fit_off + fit_n > n_local)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_ext: fit range outside the planes");
-    return pca_core(ctx, d_bands, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
+    return pca_core(ctx, (const void *const *)d_bands, false, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
                     mean, explained_variance);
 }
 
-static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
+extern "C" int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off,
+                                              int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
+                                              float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
+                                              float *explained_variance)
+{
+    if (ctx && (fit_off < 0 || fit_n < 0 || fit_off + fit_n > n_local)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca_ext: fit range outside the planes");
+    return pca_core(ctx, (const void *const *)d_bands, true, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_out, components, explained_variance_ratio,
+                    mean, explained_variance);
+}
+
+static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
                     const float *center, const double *scale, int n_components, float *const *d_out, float *components,
                     float *explained_variance_ratio, float *mean, float *explained_variance)
 {
+    const size_t esz = u8 ? 1 : 4;
     if (!ctx) return RSSEG_ERR_INVALID;
     if (!d_bands || nb < 1 || nb > PCA_MAXB || n_components < 1 || n_components > nb || n_local < 0)
         return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: bad arguments (nb=%d, n_components=%d)", nb, n_components);
@@ -333,7 +383,9 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
     // whatever the caller passes (raw DN 0-255, reflectances, ...)
     double vmin[PCA_MAXB], vmax[PCA_MAXB];
     for (int b = 0; b < nb; b++) { vmin[b] = 0.0; vmax[b] = 1.0; }
-    if (!a.normalise) {
+    if (!a.normalise && u8) {
+        for (int b = 0; b < nb; b++) { vmin[b] = 0.0; vmax[b] = 255.0; }   // any 8-bit plane
+    } else if (!a.normalise) {
         const int rgrid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div64(fit_n, PCA_THREADS * 8)));
         RSCHK(ws_reserve(ctx, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB));
         RSCHK(pin_reserve(ctx, sizeof(float) * (size_t)rgrid * 2 * PCA_MAXB));
@@ -393,10 +445,14 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
     long long *d_part = (long long *)ctx->d_ws;
     for (int si = 0; si < nseg; si++) {
         pca_args as = a;
-        for (int b = 0; b < nb; b++) as.band[b] = a.band[b] + segs[si].off;
+        for (int b = 0; b < nb; b++) as.band[b] = (const char *)a.band[b] + (size_t)segs[si].off * esz;
         prof_scope ps(ctx, "gram");
         switch (nb) {
-#define GRAM_GO(NBV) case NBV: hipLaunchKernelGGL(k3_gram<NBV>, dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff); break;
+#define GRAM_GO(NBV)                                                                                                                          \
+    case NBV:                                                                                                                                 \
+        if (u8) hipLaunchKernelGGL((k3_gram<NBV, true>), dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff);  \
+        else hipLaunchKernelGGL((k3_gram<NBV, false>), dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff);   \
+        break;
             GRAM_GO(1) GRAM_GO(2) GRAM_GO(3) GRAM_GO(4) GRAM_GO(5) GRAM_GO(6) GRAM_GO(7) GRAM_GO(8)
 #undef GRAM_GO
         }
@@ -499,8 +555,13 @@ static int pca_core(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t
             switch (nb) {
 #define PROJ_GO(NBV)                                                                                                               \
     case NBV:                                                                                                                      \
-        if (ctx->mm_collect) hipLaunchKernelGGL((k3_project<NBV, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, ctx->d_mm); \
-        else hipLaunchKernelGGL((k3_project<NBV, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, (uint32_t *)nullptr);      \
+        if (u8) {                                                                                                                  \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_project<NBV, true, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, ctx->d_mm); \
+            else hipLaunchKernelGGL((k3_project<NBV, false, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, (uint32_t *)nullptr);      \
+        } else {                                                                                                                   \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_project<NBV, true, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, ctx->d_mm); \
+            else hipLaunchKernelGGL((k3_project<NBV, false, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, n_local, (uint32_t *)nullptr);      \
+        }                                                                                                                          \
         break;
                 PROJ_GO(1) PROJ_GO(2) PROJ_GO(3) PROJ_GO(4) PROJ_GO(5) PROJ_GO(6) PROJ_GO(7) PROJ_GO(8)
 #undef PROJ_GO

@@ -56,6 +56,11 @@ SIGNATURES = {
     "rsseg_prof_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "rsseg_order_stats_f32": (_int, [_vp, _vp, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
     "rsseg_order_stats_multi_f32": (_int, [_vp, C.POINTER(_vp), _int, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
+    "rsseg_order_stats_multi_u8": (_int, [_vp, C.POINTER(_vp), _int, _i64, C.POINTER(_i64), _int, C.POINTER(C.c_float), C.POINTER(_i64)]),
+    "rsseg_spectral_indices_evi_u8": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP, C.POINTER(C.c_float)]),
+    "rsseg_pca_fit_transform_ext_u8": (_int, [_vp, _PP, _int, _i64, _i64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                              _int, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float)]),
     "rsseg_normalize_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
     "rsseg_spectral_indices_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP]),
     "rsseg_spectral_indices_evi_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP, C.POINTER(C.c_float)]),

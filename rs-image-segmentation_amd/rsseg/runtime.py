@@ -206,6 +206,21 @@ class Context:
                 return torch.from_numpy(a).to(self.device).to(torch.float32)
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
+    def upload_band(self, a: np.ndarray):
+        """A band as a flat device plane in the narrowest form the kernels take: an 8-bit raster STAYS uint8 (order
+        statistics, spectral indices and PCA read 1 byte per pixel; values identical to the float32 path on the widened
+        band), anything else becomes float32 like the reference's `.astype(np.float32)` (scripts/2:156)."""
+        torch = _torch()
+        a = np.ascontiguousarray(a).reshape(-1)
+        if a.dtype == np.uint8:
+            with torch.cuda.stream(self.torch_stream):
+                return torch.from_numpy(a).to(self.device)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    @staticmethod
+    def _is_u8(t) -> bool:
+        return t.dtype == _torch().uint8
+
     def empty(self, n, dtype):
         torch = _torch()
         t = torch.empty(int(n), dtype=dtype, device=self.device)
@@ -258,6 +273,9 @@ class Context:
 
     # ---- K1 ------------------------------------------------------------------------------------
     def order_stats(self, plane, ranks: Sequence[int]) -> Tuple[np.ndarray, int]:
+        if self._is_u8(plane):
+            v, nn = self.order_stats_multi([plane], [list(ranks)])
+            return v[0], int(nn[0])
         r = (C.c_int64 * len(ranks))(*[int(x) for x in ranks])
         out = (C.c_float * len(ranks))()
         nn = C.c_int64(0)
@@ -274,11 +292,22 @@ class Context:
         flat = (C.c_int64 * (P * R))(*[int(x) for r in ranks for x in r])
         out = (C.c_float * (P * R))()
         nn = (C.c_int64 * P)()
-        self._chk(self.lib.rsseg_order_stats_multi_f32(self.h, self._pp(planes), P, planes[0].numel(), flat, R, out, nn))
+        if any(self._is_u8(p) for p in planes):
+            if not all(self._is_u8(p) for p in planes):
+                raise ValueError("order_stats_multi: uint8 and float32 planes cannot be mixed in one call")
+            self._chk(self.lib.rsseg_order_stats_multi_u8(self.h, self._pp(planes), P, planes[0].numel(), flat, R, out, nn))
+        else:
+            self._chk(self.lib.rsseg_order_stats_multi_f32(self.h, self._pp(planes), P, planes[0].numel(), flat, R, out, nn))
         return np.array(out[:], dtype=np.float32).reshape(P, R), np.array(nn[:], dtype=np.int64)
 
     # ---- K2 ------------------------------------------------------------------------------------
     def normalize(self, plane, lo: float, hi: float, out=None):
+        torch = _torch()
+        if self._is_u8(plane):   # only the striped / NaN side paths normalise a raw band on its own: widen it first
+            with torch.cuda.stream(self.torch_stream):
+                plane = plane.to(torch.float32)
+            if getattr(self, "_async", False):
+                self._keep.append(plane)
         out = self.empty(plane.numel(), plane.dtype) if out is None else out
         self._chk(self.lib.rsseg_normalize_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo),
                                                C.c_float(hi), C.c_void_p(out.data_ptr())))
@@ -294,7 +323,11 @@ class Context:
         if lohi is not None:
             lh = (C.c_float * 10)(*[float(v) for v in np.asarray(lohi, np.float32).reshape(-1)])
         ec = None if evi_coef is None else (C.c_float * 4)(*[float(np.float32(v)) for v in evi_coef])   # {L, C1, C2, G}
-        self._chk(self.lib.rsseg_spectral_indices_evi_f32(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms), ec))
+        u8 = [self._is_u8(b) for b in bands5]
+        if any(u8) and not all(u8):
+            raise ValueError("spectral_indices: uint8 and float32 bands cannot be mixed")
+        fn = self.lib.rsseg_spectral_indices_evi_u8 if all(u8) else self.lib.rsseg_spectral_indices_evi_f32
+        self._chk(fn(self.h, self._pp(bands5), n, lh, self._pp(outs), self._pp(norms), ec))
         self._tag_minmax(outs)
         return outs, norms
 
@@ -340,7 +373,16 @@ class Context:
             lh = np.ascontiguousarray(lohi, np.float32).reshape(-1)
             if lh.size != 2 * nb:
                 raise ValueError("pca_fit_transform: lohi must hold (lo, hi) for every band")
-        if fit is not None:
+        u8 = [self._is_u8(b) for b in bands]
+        if any(u8) and not all(u8):
+            raise ValueError("pca_fit_transform: uint8 and float32 bands cannot be mixed")
+        if all(u8):
+            f0, fn_ = (0, n) if fit is None else (int(fit[0]), int(fit[1]))
+            self._chk(self.lib.rsseg_pca_fit_transform_ext_u8(self.h, self._pp(bands), nb, n, f0, fn_,
+                                                              None if lh is None else lh.ctypes.data_as(fp), cptr, sptr, n_components,
+                                                              self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),
+                                                              mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        elif fit is not None:
             self._chk(self.lib.rsseg_pca_fit_transform_ext_f32(self.h, self._pp(bands), nb, n, int(fit[0]), int(fit[1]),
                                                                None if lh is None else lh.ctypes.data_as(fp), cptr, sptr, n_components,
                                                                self._pp(outs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp),

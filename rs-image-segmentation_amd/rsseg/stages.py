@@ -28,7 +28,11 @@ def run_feature_extraction_stage(bands_data: Sequence[np.ndarray], preprocessing
     ignored exactly as in the reference (NIR = bands[3] is hard-wired, scripts/2:84)."""
     ctx = ctx or default_context()
     h, w = np.asarray(bands_data[0]).shape
-    dev = [ctx.upload_f32(np.asarray(b)) for b in bands_data if b is not None]
+    # 8-bit rasters cross PCIe as one byte per pixel and STAY one byte per pixel in HBM (Context.upload_band): the order
+    # statistics, index and PCA kernels read the uint8 planes directly; anything else is float32 as in the reference
+    arrs = [np.asarray(b) for b in bands_data if b is not None]
+    all_u8 = all(a.dtype == np.uint8 for a in arrs)
+    dev = [ctx.upload_band(a) if all_u8 else ctx.upload_f32(a) for a in arrs]
     planes, ex = P.feature_stack19(ctx, dev, h, w, preprocessing=bool(preprocessing))   # False: bands taken as given (scripts/2:43-50)
 
     def host(t):

@@ -981,6 +981,70 @@ def test_raw_band_pca_and_fused_quantise_equal_two_step_forms(ctx, crop, oracle)
         P.pca(ctx, bands, 3, True, lohi=lohi)  # raw bands need the precomputed RobustScaler statistics
 
 
+@pytest.mark.parametrize("n", [16 * 4096 + 0, 100003, 37])
+def test_uint8_planes_equal_the_widened_float32_planes(ctx, oracle, n):
+    """8-bit band planes inside K1 / K2 / K3 (1 byte per pixel instead of 4): order statistics, the seven indices (+ the
+    normalised bands), and the PCA (fit on a sub-range with an odd offset, projection of everything) are bit for bit what
+    the float32 entry points return on the widened planes — the 256-entry tables are filled with the float path's own
+    operations.  Ragged lengths (n % 16, n % 4 != 0) included."""
+    import torch
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(n)
+    raw = [np.clip(rng.normal(90 + 20 * b, 35, n), 0, 255).astype(np.uint8) for b in range(7)]
+    raw[5][: n // 3] = 7                                   # a band with a huge tie
+    d8 = [ctx.to_device(b) for b in raw]
+    d32 = [ctx.to_device(b.astype(np.float32)) for b in raw]
+    assert d8[0].dtype == torch.uint8
+    ranks = sorted({0, n - 1, n // 2, (n - 1) // 2, int(0.02 * (n - 1)), int(0.98 * (n - 1)), n // 4, (3 * n) // 4})
+    v8, nan8 = ctx.order_stats_multi(d8, [ranks] * 7)
+    v32, nan32 = ctx.order_stats_multi(d32, [ranks] * 7)
+    assert np.array_equal(v8, v32) and not nan8.any()
+    for b in range(7):
+        assert np.array_equal(v8[b], np.sort(raw[b])[ranks].astype(np.float32)), b
+    q8, q32 = P.band_quantile_bundles(ctx, d8, n), P.band_quantile_bundles(ctx, d32, n)
+    for a, b in zip(q8, q32):
+        assert all(np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes() for k in a), (a, b)
+    lohi = np.array([[q["lo"], q["hi"]] for q in q32], np.float32)
+    for lh in (lohi, None):
+        o8, n8 = ctx.spectral_indices(d8[:5], None if lh is None else lh[:5], want_norm=(True,) * 5)
+        o32, n32 = ctx.spectral_indices(d32[:5], None if lh is None else lh[:5], want_norm=(True,) * 5)
+        for a, b in zip(o8 + n8, o32 + n32):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    center = np.array([q["center"] for q in q32], np.float32)
+    scale = np.array([q["scale"] for q in q32], np.float64)
+    fit = (3, n - 8) if n > 64 else None
+    r8 = ctx.pca_fit_transform(d8, center, scale, 3, lohi, fit=fit)
+    r32 = ctx.pca_fit_transform(d32, center, scale, 3, lohi, fit=fit)
+    for a, b in zip(r8[0], r32[0]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for a, b in zip(r8[1:], r32[1:]):
+        assert np.array_equal(a, b)
+    r8n = ctx.pca_fit_transform(d8, None, None, 7)           # no RobustScaler, no normalisation: raw DN (range known: 0..255)
+    r32n = ctx.pca_fit_transform(d32, None, None, 7)
+    assert np.array_equal(r8n[1], r32n[1]) and all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(r8n[0], r32n[0]))
+
+
+def test_config3_on_uint8_bands_equals_float32_bands(ctx, oracle):
+    """The whole config-3 pipeline fed with uint8 band planes: labels, seeds, iteration count and feature planes equal
+    those of the float32 planes."""
+    import torch
+    from rsseg import pipeline as P
+    H, W = 160, 208
+    r = oracle.synthetic_raster(H, W)
+    d32 = [ctx.to_device(r[i].reshape(-1)) for i in range(7)]
+    d8 = [ctx.to_device(r[i].reshape(-1).astype(np.uint8)) for i in range(7)]
+    l32, m32, p32 = P.config3(ctx, d32, H, W, 8, 7, 1, 3)
+    l8, m8, p8 = P.config3(ctx, d8, H, W, 8, 7, 1, 3)
+    assert m8["n_iter"] == m32["n_iter"] and np.array_equal(m8["init_indices"], m32["init_indices"])
+    assert torch.equal(l8, l32)
+    for a, b in zip(p8, p32):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    s32, _ = P.feature_stack19(ctx, d32, H, W)
+    s8, _ = P.feature_stack19(ctx, d8, H, W)
+    for a, b in zip(s8, s32):
+        assert torch.equal(a, b) or torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def test_normalise_division_is_the_ieee_quotient(ctx):
     """robust_normalize's (clip(x) - lo) / (hi - lo + 1e-10) on the device: bit-equal to NumPy's float32 quotient for
     ordinary, tiny, huge and degenerate ranges, and for numerators down to the denormals (no flush to zero, no
