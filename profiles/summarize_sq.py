@@ -30,13 +30,16 @@ def main():
             continue
         waves = d.get("SQ_WAVES", 0)
         busy = 4 * d.get("SQ_ACTIVE_INST_VALU", 0) / (dur[k] * 1e-3 * 2.4e9 * 1024)
+        # MFMA utilisation: cycles with the matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES, counted in cycles) over the kernel's
+        # cycles on all SIMDs; 0 for a kernel that issues no MFMA instruction
+        mfma = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (dur[k] * 1e-3 * 2.4e9 * 1024)
         rows.append((dur[k], k, cnt[k], waves, d.get("SQ_INSTS_VALU", 0) / max(waves, 1), d.get("SQ_INSTS_LDS", 0) / max(waves, 1),
-                     d.get("SQ_WAIT_INST_ANY", 0) / max(d.get("SQ_WAVE_CYCLES", 1), 1), busy))
+                     d.get("SQ_WAIT_INST_ANY", 0) / max(d.get("SQ_WAVE_CYCLES", 1), 1), busy, d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), mfma))
     rows.sort(reverse=True)
     with open(out, "w") as fo:
-        fo.write("| kernel | launches | ms (profiled) | waves | VALU instr / wave | LDS instr / wave | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | VALU busy |\n|---|---|---|---|---|---|---|---|\n")
-        for ms, k, n, waves, vi, li, wait, busy in rows:
-            fo.write(f"| `{k}` | {n} | {ms:.2f} | {waves:.3e} | {vi:.0f} | {li:.0f} | {wait:.2f} | {busy:.2f} |\n")
+        fo.write("| kernel | launches | ms (profiled) | waves | VALU instr / wave | LDS instr / wave | SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES | VALU busy | SQ_VALU_MFMA_BUSY_CYCLES | MFMA util |\n|---|---|---|---|---|---|---|---|---|---|\n")
+        for ms, k, n, waves, vi, li, wait, busy, mraw, mfma in rows:
+            fo.write(f"| `{k}` | {n} | {ms:.2f} | {waves:.3e} | {vi:.0f} | {li:.0f} | {wait:.2f} | {busy:.2f} | {mraw:.0f} | {mfma:.3f} |\n")
 
 
 if __name__ == "__main__":
