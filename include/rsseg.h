@@ -55,7 +55,11 @@ typedef struct rsseg_ctx rsseg_ctx;
 /* All-reduce hook: reduce `count` elements of `dtype` (RSSEG_F32/F64/I64) with `op`
  * (RSSEG_SUM/MIN/MAX) IN PLACE at byte offset `offset` of the communication buffer registered with
  * rsseg_ctx_set_comm, across all ranks, ordered after the work already enqueued on the context's
- * stream.  Returns 0 on success. */
+ * stream AND before the work the library enqueues on that stream after the hook has returned: inside
+ * rsseg_kmeans_fit_predict a kernel leaves its partials in the buffer, the hook is called, and the next kernel reads
+ * the reduced values, without the host waiting in between (ncclAllReduce on the context's stream, or
+ * torch.distributed.all_reduce with that stream current, give exactly this; a hook that synchronises is also
+ * correct).  Every rank calls the hook the same number of times with the same arguments.  Returns 0 on success. */
 typedef int (*rsseg_allreduce_fn)(void *user, int64_t offset, int64_t count, int dtype, int op);
 
 /* ---- context ---------------------------------------------------------------------------- */
