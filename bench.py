@@ -107,6 +107,7 @@ def family_table(cfg, F, glcm_step, k, n_pca):
         "indices": ("hbm", 20 + idx_out),
         "normalize": ("hbm", 8), "quantize": ("hbm", 5),
         "gram": ("hbm", 28), "project": ("hbm", 28 + 4 * n_pca),
+        "indices_project": ("hbm", 28 + idx_out + 4 * n_pca),             # fused: 7 raw bands in; 7 indices (+ normalised NIR) + the components out
         "resize": ("hbm", 8),                                              # 4 taps from cache, one plane out
         "box": ("hbm", 8), "ctxmean": ("hbm", 8 * 7), "morph": ("hbm", 2), "filt_max": ("hbm", 1), "filt_write": ("hbm", 5),
         "glcm": ("valu", 4 + 20.0 / (glcm_step * glcm_step)),
@@ -123,7 +124,7 @@ MFMA_UTIL = {"value": 0.0, "note": "no MFMA instruction in the step (SQ_INSTS_MF
 
 # dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
 PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_pair",
-              "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true>", "gram": "k3_gram<7>", "project": "k3_project<7, true>",
+              "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true", "gram": "k3_gram<7", "project": "k3_project<7, true", "indices_project": "k3_indices_project<7, true",
               "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
 # static VALU instructions of the texture kernels and their measured issue cost (profiles/valu_mix.py ->
 # profiles/r02_valu_issue.json): the bound of the texture kernel is VALU issue, not HBM.  Dense case (window 7, step 1):

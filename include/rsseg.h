@@ -73,7 +73,7 @@ const char *rsseg_last_error(const rsseg_ctx *ctx);
 const char *rsseg_version(void);
 /* While on, the spectral-index call (7 index planes), the two bilinear-upsample calls (1 plane) and the PCA call
  * (n_components planes) also reduce the minimum and maximum of every plane they write, NaN counted
- * as 0 (what KMeans' MinMaxScaler sees); rsseg_ctx_last_minmax returns them, by output index, until the next such call. */
+ * as 0 (what KMeans' MinMaxScaler sees); rsseg_ctx_last_minmax returns them, by output index (at most 16), until the next such call. */
 int rsseg_ctx_collect_minmax(rsseg_ctx *ctx, int on);
 int rsseg_ctx_last_minmax(rsseg_ctx *ctx, int plane, double *mn, double *mx);
 /* Asynchronous mode: entry points whose results stay on the device (normalize, indices, quantize, glcm, resize,
@@ -88,7 +88,7 @@ int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn f
 /* Per-kernel timing (HIP events on the context's stream, around each launch of the named
  * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices", "normalize", "quantize", "range",
  * "select", "kpp", "moment" (KMeans' column means), "labels" (uint8 -> int32 label plane), "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
- * of Sobel / Laplacian), "project", "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
+ * of Sobel / Laplacian), "project", "indices_project" (the fused pass of rsseg_indices_pca_*), "gram", "forest", "resize", and "allreduce" (host wall time of the hook calls). */
 /* Number of times the library has made the host wait for the context's stream since the last reset (every result
  * read-back, every all-reduce staged through the host): what a step costs in launch-pipeline bubbles. */
 int rsseg_ctx_host_syncs(rsseg_ctx *ctx, int reset, int64_t *count);
@@ -172,6 +172,21 @@ int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands
                                    int64_t fit_n, const float *lohi, const float *center, const double *scale, int n_components,
                                    float *const *d_out, float *components, float *explained_variance_ratio, float *mean,
                                    float *explained_variance);
+/* The spectral indices AND the PCA of the same raw bands in two passes instead of three: the fit (Gram pass) as in
+ * rsseg_pca_fit_transform_ext_*, then ONE pass that writes the seven index planes d_idx[7] (ndvi, evi, msavi, ndwi, mndwi,
+ * ndbi, bsi; entries may be NULL), optionally the normalised bands d_norm[5] (may be NULL, entries may be NULL) and the
+ * n_components projected planes d_pc — the values rsseg_spectral_indices_evi_* and rsseg_pca_fit_transform_ext_* return,
+ * bit for bit (calculate_* of indices.py:50-203 and perform_pca of :205-246 on the same robust-normalised bands, as
+ * scripts/2_feature_extraction.py:63-78 calls them).  d_bands[0..4] = blue, green, red, nir, swir1; lohi[2 * nb] is required.
+ * With rsseg_ctx_collect_minmax on, rsseg_ctx_last_minmax(0..6) are the indices' extrema, (7 + c) the components'. */
+int rsseg_indices_pca_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
+                          const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
+                          float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
+                          float *explained_variance_ratio, float *mean, float *explained_variance);
+int rsseg_indices_pca_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
+                         const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
+                         float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
+                         float *explained_variance_ratio, float *mean, float *explained_variance);
 /* Errors of the PCA entry points: RSSEG_ERR_INVALID "Input X contains NaN." / "... infinity" (sklearn's PCA raises
  * ValueError on such input, sklearn/utils/validation.py); bands that are not robust-normalised are range-checked
  * with one extra pass so that the exact fixed-point accumulation fits any finite input (raw DN, reflectances). */

@@ -57,7 +57,7 @@ struct rsseg_ctx {
     bool mm_collect = false;
     uint32_t *d_mm = nullptr;  // [RSSEG_MM_REPL][RSSEG_MM_PLANES][2] ordered keys {min, max}
     int mm_count = 0;
-    double mm_min[8], mm_max[8];
+    double mm_min[16], mm_max[16];
     // host synchronisations (hipStreamSynchronize / blocking copies) the library has made on this context (rsseg_ctx_host_syncs)
     long long host_syncs = 0;
 };
@@ -69,7 +69,7 @@ static inline hipError_t rs_sync(rsseg_ctx *ctx)
 }
 // moves the last `count` recorded launches of family `from` to family `to` (speculative launches that turned out to be no-ops)
 void prof_retag(rsseg_ctx *ctx, const char *from, int count, const char *to);
-#define RSSEG_MM_PLANES 8
+#define RSSEG_MM_PLANES 16
 #define RSSEG_MM_REPL 64   // replicas of the slot table, one 64-byte line each: a workgroup commits to replica blockIdx.x % 64
 int mm_begin(rsseg_ctx *ctx, int nplanes);   // reset the device slots before a producing launch (no-op when off)
 int mm_end(rsseg_ctx *ctx, int nplanes);     // read them back into ctx->mm_min / mm_max (after the launch)
@@ -197,6 +197,49 @@ __device__ __forceinline__ void mm_commit_wg(uint32_t *slot, float mn, float mx)
         if (kmx > __builtin_nontemporal_load(&rs[1])) atomicMax(&rs[1], kmx);
     }
     __syncthreads();
+}
+
+// ---- the seven spectral indices of one pixel (indices.py:62-69, 86-93, 109-112, 128-135, 150-156, 171-177, 194-201) ------------
+// shared by k2_indices and the fused index + PCA-projection kernel of k3_pca.hip; one IEEE float32 operation per NumPy operation
+__device__ __forceinline__ float clip11(float v)
+{
+    v = v < -1.0f ? -1.0f : v;
+    return v > 1.0f ? 1.0f : v;
+}
+__device__ __forceinline__ float ratio_index(float num, float den)
+{
+    // zeros_like; out[mask] = num/den with mask = den > 0.001 (False for NaN); clip to [-1, 1]
+    float v = den > 0.001f ? num / den : 0.0f;
+    return clip11(v);
+}
+struct evi_coef_t {
+    float L, C1, C2, G;   // calculate_evi's coefficients (defaults 1, 6, 7.5, 2.5), as float32 like NumPy's weak scalars
+};
+// nb: normalised blue, green, red, nir, swir1;  o: ndvi, evi, msavi, ndwi, mndwi, ndbi, bsi
+__device__ __forceinline__ void indices_pixel(const evi_coef_t &e, const float nb[5], float o[7])
+{
+    const float blue = nb[0], green = nb[1], red = nb[2], nir = nb[3], swir = nb[4];
+    const float nmr = nir - red;
+    o[0] = ratio_index(nmr, nir + red);
+    {   // indices.py:86-93  nir + C1*red - C2*blue + L ;  G*(nir-red)/den
+        float den = nir + e.C1 * red;
+        den = den - e.C2 * blue;
+        den = den + e.L;
+        o[1] = ratio_index(e.G * nmr, den);
+    }
+    {   // indices.py:109-112  (a - sqrt(a**2 - 8*(nir-red))) / 2
+        const float a = 2.0f * nir + 1.0f;
+        float r = a * a - 8.0f * nmr;
+        float m = (a - sqrtf(r)) / 2.0f;
+        o[2] = clip11(m);  // NaN propagates like np.clip
+    }
+    o[3] = ratio_index(green - nir, green + nir);
+    o[4] = ratio_index(green - swir, green + swir);
+    o[5] = ratio_index(swir - nir, swir + nir);
+    {
+        const float a = swir + red, b = nir + blue;
+        o[6] = ratio_index(a - b, a + b);
+    }
 }
 
 // round-to-nearest-even fixed point, quantum 2^-40, exact for |x| < 2^11:

@@ -7,53 +7,17 @@
 
 #define K2_THREADS 256
 
-__device__ __forceinline__ float clip11(float v)
-{
-    v = v < -1.0f ? -1.0f : v;
-    return v > 1.0f ? 1.0f : v;
-}
-__device__ __forceinline__ float ratio_index(float num, float den)
-{
-    // zeros_like; out[mask] = num/den with mask = den > 0.001 (False for NaN); clip to [-1, 1]
-    float v = den > 0.001f ? num / den : 0.0f;
-    return clip11(v);
-}
-
 struct k2_args {
     const void *band[5];   // float32 planes, or uint8 planes (k2_indices<.., true>)
     float *out[7];
     float *norm[5];
     float lo[5], hi[5], den[5];
     int normalise;
-    float evi_L, evi_C1, evi_C2, evi_G;   // calculate_evi's coefficients (defaults 1, 6, 7.5, 2.5), as float32 like NumPy's weak scalars
+    evi_coef_t evi;
 };
 
 // o: ndvi, evi, msavi, ndwi, mndwi, ndbi, bsi
-__device__ __forceinline__ void k2_pixel(const k2_args &a, const float nb[5], float o[7])
-{
-    const float blue = nb[0], green = nb[1], red = nb[2], nir = nb[3], swir = nb[4];
-    const float nmr = nir - red;
-    o[0] = ratio_index(nmr, nir + red);
-    {   // indices.py:86-93  nir + C1*red - C2*blue + L ;  G*(nir-red)/den
-        float den = nir + a.evi_C1 * red;
-        den = den - a.evi_C2 * blue;
-        den = den + a.evi_L;
-        o[1] = ratio_index(a.evi_G * nmr, den);
-    }
-    {   // indices.py:109-112  (a - sqrt(a**2 - 8*(nir-red))) / 2
-        const float a = 2.0f * nir + 1.0f;
-        float r = a * a - 8.0f * nmr;
-        float m = (a - sqrtf(r)) / 2.0f;
-        o[2] = clip11(m);  // NaN propagates like np.clip
-    }
-    o[3] = ratio_index(green - nir, green + nir);
-    o[4] = ratio_index(green - swir, green + swir);
-    o[5] = ratio_index(swir - nir, swir + nir);
-    {
-        const float a = swir + red, b = nir + blue;
-        o[6] = ratio_index(a - b, a + b);
-    }
-}
+__device__ __forceinline__ void k2_pixel(const k2_args &a, const float nb[5], float o[7]) { indices_pixel(a.evi, nb, o); }
 
 // MM: also reduce min / max of the 7 index planes into mm[j] (rsseg_ctx_collect_minmax)
 // U8: the bands are 8-bit planes (1 byte per pixel instead of 4).  A byte has 256 values, so robust_normalize of a band is a
@@ -252,10 +216,10 @@ static int indices_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int
         }
     }
     a.normalise = lohi != nullptr;
-    a.evi_L = evi_coef ? evi_coef[0] : 1.0f;
-    a.evi_C1 = evi_coef ? evi_coef[1] : 6.0f;
-    a.evi_C2 = evi_coef ? evi_coef[2] : 7.5f;
-    a.evi_G = evi_coef ? evi_coef[3] : 2.5f;
+    a.evi.L = evi_coef ? evi_coef[0] : 1.0f;
+    a.evi.C1 = evi_coef ? evi_coef[1] : 6.0f;
+    a.evi.C2 = evi_coef ? evi_coef[2] : 7.5f;
+    a.evi.G = evi_coef ? evi_coef[3] : 2.5f;
     for (int j = 0; j < 7; j++) {
         a.out[j] = d_out[j];
         if (a.out[j] && ((uintptr_t)a.out[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "spectral_indices: output plane unaligned");

@@ -268,6 +268,157 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
     }
 }
 
+// Fused: the seven spectral indices (K2) AND the projection on the principal components in ONE pass over the raw bands
+// (both read the same robust-normalised values: the five bands the indices use are normalised once instead of twice and
+// read once instead of twice — 28 B/px in, 28 + 4 (normalised NIR) + 4 nc out, against 20 + 32 and 28 + 4 nc).  Bands 0..4
+// are blue, green, red, nir, swir1 (the reference's TM order).  Extrema slots (MM): 0..6 the indices, 7.. the components.
+struct fuse_args {
+    float *idx[7];
+    float *norm[5];
+    evi_coef_t evi;
+};
+
+template <int NB, bool MM, bool U8>
+__global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, proj_args pr, fuse_args fz, int64_t n, uint32_t *__restrict__ mm)
+{
+    static_assert(NB >= 5, "the indices read bands 0..4");
+    __shared__ float lutn[U8 ? 5 * 256 : 1];    // robust_normalize of a byte (bands 0..4)
+    __shared__ float lutx[U8 ? NB * 256 : 1];   // pca_x of a byte
+    if (U8) {
+        for (int i = threadIdx.x; i < 5 * 256; i += PCA_THREADS) lutn[i] = norm1((float)(i & 255), a.nlo[i >> 8], a.nhi[i >> 8], a.nden[i >> 8]);
+        for (int i = threadIdx.x; i < NB * 256; i += PCA_THREADS) lutx[i] = pca_x(a, i >> 8, (float)(i & 255));
+        __syncthreads();
+    }
+    // pca_x on an already normalised value (the second half of pca_x)
+    auto scale_x = [&](int b, float v) -> float {
+        if (!a.scaled) return v;
+        const float d = v - a.center[b];
+        if (a.slow_div) return (float)((double)d / a.scale[b]);
+        const double sc = a.scale[b], y = a.rinv[b];
+        const double q = (double)d * y;
+        const double r = fma(-q, sc, (double)d);
+        return (float)fma(r, y, q);
+    };
+    const int64_t n4 = n >> 2;
+    float lmn[7 + PCA_MAXB], lmx[7 + PCA_MAXB];
+#pragma unroll
+    for (int c = 0; c < 7 + PCA_MAXB; c++) { lmn[c] = INFINITY; lmx[c] = -INFINITY; }
+    auto track = [&](int slot, float v) {
+        const float z = v != v ? 0.f : v;
+        lmn[slot] = fminf(lmn[slot], z);
+        lmx[slot] = fmaxf(lmx[slot], z);
+    };
+    for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
+        float nbv[4][5], x[4][NB];
+        if (U8) {
+            uint32_t w[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t v = (w[b] >> (8 * p)) & 255u;
+                    x[p][b] = lutx[b * 256 + v];
+                    if (b < 5) nbv[p][b] = lutn[b * 256 + v];
+                }
+        } else {
+            float4 v[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float vv[4] = {v[b].x, v[b].y, v[b].z, v[b].w};
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float nv = norm1(vv[p], a.nlo[b], a.nhi[b], a.nden[b]);
+                    if (b < 5) nbv[p][b] = nv;
+                    x[p][b] = scale_x(b, nv);
+                }
+            }
+        }
+        float o[4][7];
+#pragma unroll
+        for (int p = 0; p < 4; p++) indices_pixel(fz.evi, nbv[p], o[p]);
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            if (fz.idx[j]) reinterpret_cast<float4 *>(fz.idx[j])[i] = make_float4(o[0][j], o[1][j], o[2][j], o[3][j]);
+            if (MM) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) track(j, o[p][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (fz.norm[j]) reinterpret_cast<float4 *>(fz.norm[j])[i] = make_float4(nbv[0][j], nbv[1][j], nbv[2][j], nbv[3][j]);
+#pragma nounroll
+        for (int c = 0; c < pr.nc; c++) {
+            float y[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                float s = 0.f;
+#pragma unroll
+                for (int b = 0; b < NB; b++) s = __fmaf_rn(x[p][b], pr.comp[c][b], s);
+                y[p] = s - pr.offs[c];
+            }
+            reinterpret_cast<float4 *>(pr.out[c])[i] = make_float4(y[0], y[1], y[2], y[3]);
+            if (MM) {
+#pragma unroll
+                for (int cc = 0; cc < PCA_MAXB; cc++)   // static indices: the arrays stay in registers
+                    if (cc == c) {
+#pragma unroll
+                        for (int p = 0; p < 4; p++) track(7 + cc, y[p]);
+                    }
+            }
+        }
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
+    if (t < n) {
+        float nbv[5], x[NB], o[7];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (U8) {
+                const uint32_t v = reinterpret_cast<const uint8_t *>(a.band[b])[t];
+                x[b] = lutx[b * 256 + v];
+                if (b < 5) nbv[b] = lutn[b * 256 + v];
+            } else {
+                const float nv = norm1(reinterpret_cast<const float *>(a.band[b])[t], a.nlo[b], a.nhi[b], a.nden[b]);
+                if (b < 5) nbv[b] = nv;
+                x[b] = scale_x(b, nv);
+            }
+        }
+        indices_pixel(fz.evi, nbv, o);
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            if (fz.idx[j]) fz.idx[j][t] = o[j];
+            if (MM) track(j, o[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (fz.norm[j]) fz.norm[j][t] = nbv[j];
+#pragma nounroll
+        for (int c = 0; c < pr.nc; c++) {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; b++) s = __fmaf_rn(x[b], pr.comp[c][b], s);
+            const float yv = s - pr.offs[c];
+            pr.out[c][t] = yv;
+            if (MM) {
+#pragma unroll
+                for (int cc = 0; cc < PCA_MAXB; cc++)
+                    if (cc == c) track(7 + cc, yv);
+            }
+        }
+    }
+    if (MM) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) mm_commit_wg(mm + 2 * j, lmn[j], lmx[j]);
+#pragma unroll
+        for (int cc = 0; cc < PCA_MAXB; cc++)
+            if (cc < pr.nc) mm_commit_wg(mm + 2 * (7 + cc), lmn[7 + cc], lmx[7 + cc]);
+    }
+}
+
 // cyclic Jacobi for a small symmetric matrix (float64).  V columns = eigenvectors.
 static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][PCA_MAXB], double *w)
 {
@@ -304,9 +455,14 @@ static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][
     for (int i = 0; i < n; i++) w[i] = A[i][i];
 }
 
+struct fuse_req {   // non-null: produce the spectral indices (+ normalised bands) in the projection pass
+    float *const *d_idx;
+    float *const *d_norm;
+    const float *evi_coef;
+};
 static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
                     const float *center, const double *scale, int n_components, float *const *d_out, float *components,
-                    float *explained_variance_ratio, float *mean, float *explained_variance);
+                    float *explained_variance_ratio, float *mean, float *explained_variance, const fuse_req *fuse = nullptr);
 
 extern "C" int rsseg_pca_fit_transform_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local,
                                            const float *center, const double *scale, int n_components, float *const *d_out,
@@ -347,9 +503,45 @@ extern "C" int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *con
                     mean, explained_variance);
 }
 
+static int indices_pca_entry(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
+                             const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
+                             float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components, float *explained_variance_ratio,
+                             float *mean, float *explained_variance)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (nb < 5) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: the indices need bands 0..4 (blue, green, red, nir, swir1)");
+    if (!lohi || !d_idx || !d_pc) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: lohi, index planes and component planes are required");
+    if (fit_off < 0 || fit_n < 0 || fit_off + fit_n > n_local) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: fit range outside the planes");
+    for (int j = 0; j < 7; j++)
+        if (d_idx[j] && ((uintptr_t)d_idx[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: index plane %d unaligned", j);
+    for (int j = 0; j < 5; j++)
+        if (d_norm && d_norm[j] && ((uintptr_t)d_norm[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: norm plane %d unaligned", j);
+    const fuse_req fr = {d_idx, d_norm, evi_coef};
+    return pca_core(ctx, d_bands, u8, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_pc, components, explained_variance_ratio, mean,
+                    explained_variance, &fr);
+}
+
+extern "C" int rsseg_indices_pca_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
+                                     const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
+                                     float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
+                                     float *explained_variance_ratio, float *mean, float *explained_variance)
+{
+    return indices_pca_entry(ctx, (const void *const *)d_bands, false, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, evi_coef, d_idx, d_norm,
+                             d_pc, components, explained_variance_ratio, mean, explained_variance);
+}
+
+extern "C" int rsseg_indices_pca_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
+                                    const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
+                                    float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
+                                    float *explained_variance_ratio, float *mean, float *explained_variance)
+{
+    return indices_pca_entry(ctx, (const void *const *)d_bands, true, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, evi_coef, d_idx, d_norm,
+                             d_pc, components, explained_variance_ratio, mean, explained_variance);
+}
+
 static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
                     const float *center, const double *scale, int n_components, float *const *d_out, float *components,
-                    float *explained_variance_ratio, float *mean, float *explained_variance)
+                    float *explained_variance_ratio, float *mean, float *explained_variance, const fuse_req *fuse)
 {
     const size_t esz = u8 ? 1 : 4;
     if (!ctx) return RSSEG_ERR_INVALID;
@@ -547,7 +739,38 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
     }
     if (mean)
         for (int b = 0; b < nb; b++) mean[b] = mu[b];
-    if (d_out && n_local > 0) {
+    if (d_out && n_local > 0 && fuse) {
+        fuse_args fz;
+        memset(&fz, 0, sizeof(fz));
+        for (int j = 0; j < 7; j++) fz.idx[j] = fuse->d_idx[j];
+        for (int j = 0; j < 5; j++) fz.norm[j] = fuse->d_norm ? fuse->d_norm[j] : nullptr;
+        fz.evi.L = fuse->evi_coef ? fuse->evi_coef[0] : 1.0f;
+        fz.evi.C1 = fuse->evi_coef ? fuse->evi_coef[1] : 6.0f;
+        fz.evi.C2 = fuse->evi_coef ? fuse->evi_coef[2] : 7.5f;
+        fz.evi.G = fuse->evi_coef ? fuse->evi_coef[3] : 2.5f;
+        RSCHK(mm_begin(ctx, 7 + n_components));
+        {
+            prof_scope ps(ctx, "indices_project");
+            const dim3 pg((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
+            switch (nb) {
+#define FUSE_GO(NBV)                                                                                                                   \
+    case NBV:                                                                                                                          \
+        if (u8) {                                                                                                                      \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm); \
+            else hipLaunchKernelGGL((k3_indices_project<NBV, false, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr);      \
+        } else {                                                                                                                       \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm); \
+            else hipLaunchKernelGGL((k3_indices_project<NBV, false, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr);      \
+        }                                                                                                                              \
+        break;
+                FUSE_GO(5) FUSE_GO(6) FUSE_GO(7) FUSE_GO(8)
+#undef FUSE_GO
+            default: return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: %d bands", nb);
+            }
+        }
+        HIPCHK(ctx, hipGetLastError());
+        RSCHK(mm_end(ctx, 7 + n_components));
+    } else if (d_out && n_local > 0) {
         RSCHK(mm_begin(ctx, n_components));
         {
             prof_scope ps(ctx, "project");

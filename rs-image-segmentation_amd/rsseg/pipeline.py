@@ -110,6 +110,17 @@ def pca(ctx: Context, norm_bands: Sequence, n_components: Optional[int] = None, 
     return outs, ratio, dict(components=comp, mean=mean, explained_variance=ev, center=center, scale=scale)
 
 
+def indices_and_pca(ctx: Context, bands: Sequence, qb: Sequence[dict], lohi: np.ndarray, n_components: Optional[int], want_norm=(False,) * 5,
+                    fit: Optional[Tuple[int, int]] = None):
+    """The seven indices and perform_pca of the same raw bands through the fused entry point (one Gram pass + ONE pass that
+    writes indices, wanted normalised bands and components): (idx dict, norms, pcs, ratio, model)."""
+    nc = len(bands) if n_components is None else n_components
+    center = np.array([q["center"] for q in qb], np.float32)
+    scale = np.array([q["scale"] for q in qb], np.float64)
+    idx, norms, pcs, comp, ratio, mean, ev = ctx.indices_pca(list(bands), lohi, center, scale, nc, want_norm=want_norm, fit=fit)
+    return dict(zip(INDEX_NAMES, idx)), norms, pcs, ratio, dict(components=comp, mean=mean, explained_variance=ev, center=center, scale=scale)
+
+
 def renormalize(ctx: Context, plane, n_global: Optional[int] = None):
     """The texture functions re-apply robust_normalize to the band they receive (indices.py:265, 333,
     412, 455, 531)."""
@@ -150,8 +161,7 @@ def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=2
         if fused:
             # one grouped select serves every percentile; the PCA normalises the RAW bands inside its kernels (no
             # normalised planes are written, no range pass), only the normalised NIR band is kept for the texture chain
-            idx, norms = spectral_indices(ctx, bands, lohi, want_norm=tuple(i == 3 for i in range(5)))
-            pcs, ratio, model = pca(ctx, bands, None, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
+            idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, None, want_norm=tuple(i == 3 for i in range(5)))
             nir2 = ctx.normalize(norms[3], float(qb[3]["lo2"]), float(qb[3]["hi2"]), out=norms[3])
             norm_all = None
         else:  # a band with NaNs: separate selects on the normalised planes
@@ -236,14 +246,15 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
         lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
         fused = all(q["center"] is not None for q in qb)
         want = tuple(i == NIR for i in range(5)) if fused else (True,) * 5
-        idx, norms = spectral_indices(ctx, bands, lohi, want_norm=want)
-        if fused:
+        if fused:   # indices + PCA straight from the RAW bands: one Gram pass, one pass that writes indices, normalised NIR and components
+            idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca, want_norm=want)
             lo2, hi2 = qb[NIR]["lo2"], qb[NIR]["hi2"]
         else:
+            idx, norms = spectral_indices(ctx, bands, lohi, want_norm=want)
             lo2, hi2 = band_percentiles(ctx, norms[NIR], (2, 98), n_global)
         glcm, _ = glcm_features(ctx, norms[NIR], H, W, 32, glcm_window, glcm_step, renorm=(lo2, hi2))
         if fused:
-            pcs, ratio, model = pca(ctx, bands, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
+            pass
         else:  # a band with NaNs: separate selects on the normalised planes
             norm_all = list(norms) + [ctx.normalize(bands[i], float(lohi[i, 0]), float(lohi[i, 1])) for i in range(5, len(bands))]
             pcs, ratio, model = pca(ctx, norm_all, n_pca, True, n_global, None)
@@ -317,9 +328,8 @@ def config3_striped(ctx: Context, bands: Sequence, nir_ext, H: int, W: int, r0: 
     qb = band_quantile_bundles(ctx, bands, n_global)
     lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
     fused = all(q["center"] is not None for q in qb)
-    if fused:   # PCA straight from the raw stripes; no normalised planes are written
-        idx, _ = spectral_indices(ctx, bands, lohi)
-        pcs, ratio, model = pca(ctx, bands, n_pca, True, n_global, [(q["center"], q["scale"]) for q in qb], lohi=lohi)
+    if fused:   # indices + PCA straight from the raw stripes; no normalised planes are written
+        idx, _, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca)
         lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
     else:
         idx, norms = spectral_indices(ctx, bands, lohi, want_norm=(True,) * 5)
@@ -387,11 +397,8 @@ def stack19_striped(ctx: Context, bands_ext: Sequence, H: int, W: int, r0: int, 
     bc = [_rows_view(b, W, c0 - e0, c1 - e0) for b in bands_ext]
     fit = ((r0 - c0) * W, (r1 - r0) * W)
     if fused:
-        idx, _ = spectral_indices(ctx, bc, lohi)
-        stats = [(q["center"], q["scale"]) for q in qb]
-        center = np.array([s[0] for s in stats], np.float32)
-        scale = np.array([s[1] for s in stats], np.float64)
-        pcs, comp, ratio, mean, ev = ctx.pca_fit_transform(bc, center, scale, len(bc), lohi, fit=fit)
+        idx, _, pcs, ratio, model_ = indices_and_pca(ctx, bc, qb, lohi, len(bc), fit=fit)
+        comp, mean, ev, center, scale = model_["components"], model_["mean"], model_["explained_variance"], model_["center"], model_["scale"]
         lo2, hi2 = qb[3]["lo2"], qb[3]["hi2"]
     else:  # a band with NaNs: RobustScaler statistics by separate selects on the normalised stripes
         idx, norms = spectral_indices(ctx, bc, lohi, want_norm=(True,) * 5)

@@ -398,6 +398,38 @@ class Context:
         self._tag_minmax(outs)
         return outs, comp, ratio, mean, ev
 
+    def indices_pca(self, bands: Sequence, lohi: np.ndarray, center: Optional[np.ndarray], scale: Optional[np.ndarray], n_components: int,
+                    want_norm: Sequence[bool] = (False,) * 5, fit: Optional[Tuple[int, int]] = None, evi_coef: Optional[Sequence[float]] = None):
+        """The seven spectral indices and the PCA of the same RAW bands with one pass less than spectral_indices +
+        pca_fit_transform (rsseg_indices_pca_*): returns (index planes [7], normalised bands [5] (None where not wanted),
+        component planes, components, ratio, mean, explained_variance) — the same bits as the two separate calls."""
+        torch = _torch()
+        nb, n = len(bands), bands[0].numel()
+        idx = [self.empty(n, torch.float32) for _ in range(7)]
+        norms = [self.empty(n, torch.float32) if w else None for w in want_norm]
+        pcs = [self.empty(n, torch.float32) for _ in range(n_components)]
+        comp = np.zeros((n_components, nb), np.float32)
+        ratio = np.zeros(n_components, np.float32)
+        mean = np.zeros(nb, np.float32)
+        ev = np.zeros(n_components, np.float32)
+        fp = C.POINTER(C.c_float)
+        lh = np.ascontiguousarray(lohi, np.float32).reshape(-1)
+        if lh.size != 2 * nb:
+            raise ValueError("indices_pca: lohi must hold (lo, hi) for every band")
+        cptr = None if center is None else np.ascontiguousarray(center, np.float32).ctypes.data_as(fp)
+        sc64 = None if scale is None else np.ascontiguousarray(scale, np.float64)
+        sptr = None if sc64 is None else sc64.ctypes.data_as(C.POINTER(C.c_double))
+        ec = None if evi_coef is None else (C.c_float * 4)(*[float(np.float32(v)) for v in evi_coef])
+        u8 = [self._is_u8(b) for b in bands]
+        if any(u8) and not all(u8):
+            raise ValueError("indices_pca: uint8 and float32 bands cannot be mixed")
+        f0, fn_ = (0, n) if fit is None else (int(fit[0]), int(fit[1]))
+        fn = self.lib.rsseg_indices_pca_u8 if all(u8) else self.lib.rsseg_indices_pca_f32
+        self._chk(fn(self.h, self._pp(bands), nb, n, f0, fn_, lh.ctypes.data_as(fp), cptr, sptr, n_components, ec, self._pp(idx), self._pp(norms),
+                     self._pp(pcs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp), mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+        self._tag_minmax(idx + pcs)
+        return idx, norms, pcs, comp, ratio, mean, ev
+
     # ---- K4..K8 --------------------------------------------------------------------------------
     def glcm(self, q, H: int, W: int, levels: int, win: int, step: int):
         torch = _torch()

@@ -1024,6 +1024,40 @@ def test_uint8_planes_equal_the_widened_float32_planes(ctx, oracle, n):
     assert np.array_equal(r8n[1], r32n[1]) and all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(r8n[0], r32n[0]))
 
 
+@pytest.mark.parametrize("n,u8", [(100003, False), (4096 * 16, True), (100003, True), (41, False)])
+def test_fused_indices_pca_equals_the_two_separate_calls(ctx, oracle, n, u8):
+    """rsseg_indices_pca_* (one Gram pass + one pass writing indices, normalised bands and components) against
+    rsseg_spectral_indices_evi_* + rsseg_pca_fit_transform_ext_*: every plane, the model and the extrema tags bit for bit;
+    float32 and uint8 bands, ragged lengths, a fit range with an odd offset, 3 and 7 components, non-default EVI coefficients."""
+    import torch
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(n + u8)
+    raw = [np.clip(rng.normal(80 + 15 * b, 30, n), 0, 255).astype(np.uint8) for b in range(7)]
+    if not u8:
+        raw = [(b.astype(np.float32) + rng.random(n).astype(np.float32) * 0.7).astype(np.float32) for b in raw]   # general floats
+    d = [ctx.to_device(b) for b in raw]
+    qb = P.band_quantile_bundles(ctx, d, n)
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+    center = np.array([q["center"] for q in qb], np.float32)
+    scale = np.array([q["scale"] for q in qb], np.float64)
+    fit = (5, n - 9) if n > 64 else None
+    ctx.collect_minmax(True)
+    try:
+        for nc, evi in ((3, None), (7, (0.5, 5.0, 6.5, 2.0))):
+            idx_s, norm_s = ctx.spectral_indices(d[:5], lohi[:5], want_norm=(True,) * 5, evi_coef=evi)
+            tags_s = [t._rsseg_minmax for t in idx_s]
+            pc_s, comp_s, ratio_s, mean_s, ev_s = ctx.pca_fit_transform(d, center, scale, nc, lohi, fit=fit)
+            tags_s += [t._rsseg_minmax for t in pc_s]
+            idx_f, norm_f, pc_f, comp_f, ratio_f, mean_f, ev_f = ctx.indices_pca(d, lohi, center, scale, nc, want_norm=(True,) * 5, fit=fit, evi_coef=evi)
+            tags_f = [t._rsseg_minmax for t in idx_f + pc_f]
+            for a, b in zip(idx_s + norm_s + pc_s, idx_f + norm_f + pc_f):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+            assert np.array_equal(comp_s, comp_f) and np.array_equal(ratio_s, ratio_f) and np.array_equal(mean_s, mean_f) and np.array_equal(ev_s, ev_f)
+            assert tags_s == tags_f
+    finally:
+        ctx.collect_minmax(False)
+
+
 def test_config3_on_uint8_bands_equals_float32_bands(ctx, oracle):
     """The whole config-3 pipeline fed with uint8 band planes: labels, seeds, iteration count and feature planes equal
     those of the float32 planes."""
