@@ -141,6 +141,25 @@ def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size
     return dict(zip(GLCM_NAMES, ctx.resize_bilinear_multi(small, oh, ow, 0, oh, H, W, 0, H))), (oh, ow)   # five maps, one launch
 
 
+def _async_pipeline(fn):
+    """Entry points whose results stay on the device do not wait for the stream inside the pipeline (rsseg_ctx_set_async);
+    the calls that hand values to the host wait by themselves."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args, **kwargs):
+        was_async = getattr(ctx, "_async", False)
+        if not was_async:
+            ctx.set_async(True)
+        try:
+            return fn(ctx, *args, **kwargs)
+        finally:
+            if not was_async:
+                ctx.end_async()
+    return wrapped
+
+
+@_async_pipeline
 def feature_stack19(ctx: Context, bands: Sequence, H: int, W: int, glcm_window=21, glcm_step=21, glcm_levels=32,
                     n_global: Optional[int] = None, preprocessing: bool = True):
     """The 19 planes of hierarchical_features['all'] (scripts/2:112-127), in stack order.
@@ -376,6 +395,7 @@ def _rows_view(t, W: int, a: int, b: int):
     return v if v.data_ptr() % 16 == 0 else v.clone()
 
 
+@_async_pipeline
 def stack19_striped(ctx: Context, bands_ext: Sequence, H: int, W: int, r0: int, r1: int, e0: int, glcm_window=21, glcm_step=21,
                     glcm_levels=32):
     """feature_stack19 for the rank that owns rows [r0, r1) of ONE H x W raster.  `bands_ext`: rows [e0, e1) of every
