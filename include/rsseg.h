@@ -178,15 +178,18 @@ int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands
  * n_components projected planes d_pc — the values rsseg_spectral_indices_evi_* and rsseg_pca_fit_transform_ext_* return,
  * bit for bit (calculate_* of indices.py:50-203 and perform_pca of :205-246 on the same robust-normalised bands, as
  * scripts/2_feature_extraction.py:63-78 calls them).  d_bands[0..4] = blue, green, red, nir, swir1; lohi[2 * nb] is required.
+ * d_q (optional): the texture chain's input in the same pass — rsseg_normalize_quantize_u8 of the normalised NIR band
+ * (band 3) with the percentiles q_lo, q_hi of THAT normalised band and the multiplier q_mult (levels - 1 or 255):
+ * calculate_glcm_features re-normalises the band it receives and truncates it to uint8 (indices.py:265-268).
  * With rsseg_ctx_collect_minmax on, rsseg_ctx_last_minmax(0..6) are the indices' extrema, (7 + c) the components'. */
 int rsseg_indices_pca_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
                           const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
-                          float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
-                          float *explained_variance_ratio, float *mean, float *explained_variance);
+                          float *const *d_idx, float *const *d_norm, float *const *d_pc, uint8_t *d_q, float q_lo, float q_hi,
+                          float q_mult, float *components, float *explained_variance_ratio, float *mean, float *explained_variance);
 int rsseg_indices_pca_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
                          const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
-                         float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
-                         float *explained_variance_ratio, float *mean, float *explained_variance);
+                         float *const *d_idx, float *const *d_norm, float *const *d_pc, uint8_t *d_q, float q_lo, float q_hi,
+                         float q_mult, float *components, float *explained_variance_ratio, float *mean, float *explained_variance);
 /* Errors of the PCA entry points: RSSEG_ERR_INVALID "Input X contains NaN." / "... infinity" (sklearn's PCA raises
  * ValueError on such input, sklearn/utils/validation.py); bands that are not robust-normalised are range-checked
  * with one extra pass so that the exact fixed-point accumulation fits any finite input (raw DN, reflectances). */

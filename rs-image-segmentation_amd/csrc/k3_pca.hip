@@ -90,10 +90,14 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            acc[b] += (unsigned long long)__double_as_longlong(fma((double)x[b], a.fx_scale, FX_MAGIC));
+            // xs = x_b * 2^Q is exact (a power of two), and so is the product xs * x_c inside the fma (two float32 values: 48 bits):
+            // fma(xs, x_c, MAGIC) rounds x_b * x_c * 2^Q to an integer ONCE, like fma(x_b * x_c, 2^Q, MAGIC) with its exact float64
+            // product did — the same bits for one float64 multiplication less per term
+            const double xs = (double)x[b] * a.fx_scale;
+            acc[b] += (unsigned long long)__double_as_longlong(xs + FX_MAGIC);
 #pragma unroll
-            for (int c = b; c < NB; c++)  // the product of two float32 values is exact in float64
-                acc[pca_tri(b, c)] += (unsigned long long)__double_as_longlong(fma((double)x[b] * (double)x[c], a.fx_scale, FX_MAGIC));
+            for (int c = b; c < NB; c++)
+                acc[pca_tri(b, c)] += (unsigned long long)__double_as_longlong(fma(xs, (double)x[c], FX_MAGIC));
         }
         cnt++;
     };
@@ -276,6 +280,10 @@ struct fuse_args {
     float *idx[7];
     float *norm[5];
     evi_coef_t evi;
+    // optional: the texture chain's input — trunc(robust_normalize(normalised NIR; q_lo, q_hi) * q_mult) as uint8
+    // (calculate_glcm_features re-normalises the band it receives and quantises it, indices.py:265-268)
+    uint8_t *q;
+    float q_lo, q_hi, q_den, q_mult;
 };
 
 template <int NB, bool MM, bool U8>
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
     static_assert(NB >= 5, "the indices read bands 0..4");
     __shared__ float lutn[U8 ? 5 * 256 : 1];    // robust_normalize of a byte (bands 0..4)
     __shared__ float lutx[U8 ? NB * 256 : 1];   // pca_x of a byte
+    auto quant = [&](float nir_norm) -> uint32_t { return (uint32_t)(uint8_t)(int)(norm1(nir_norm, fz.q_lo, fz.q_hi, fz.q_den) * fz.q_mult); };
     if (U8) {
         for (int i = threadIdx.x; i < 5 * 256; i += PCA_THREADS) lutn[i] = norm1((float)(i & 255), a.nlo[i >> 8], a.nhi[i >> 8], a.nden[i >> 8]);
         for (int i = threadIdx.x; i < NB * 256; i += PCA_THREADS) lutx[i] = pca_x(a, i >> 8, (float)(i & 255));
@@ -351,6 +360,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
 #pragma unroll
         for (int j = 0; j < 5; j++)
             if (fz.norm[j]) reinterpret_cast<float4 *>(fz.norm[j])[i] = make_float4(nbv[0][j], nbv[1][j], nbv[2][j], nbv[3][j]);
+        if (fz.q) reinterpret_cast<uint32_t *>(fz.q)[i] = quant(nbv[0][3]) | (quant(nbv[1][3]) << 8) | (quant(nbv[2][3]) << 16) | (quant(nbv[3][3]) << 24);
 #pragma nounroll
         for (int c = 0; c < pr.nc; c++) {
             float y[4];
@@ -396,6 +406,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
 #pragma unroll
         for (int j = 0; j < 5; j++)
             if (fz.norm[j]) fz.norm[j][t] = nbv[j];
+        if (fz.q) fz.q[t] = (uint8_t)quant(nbv[3]);
 #pragma nounroll
         for (int c = 0; c < pr.nc; c++) {
             float s = 0.f;
@@ -455,10 +466,12 @@ static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][
     for (int i = 0; i < n; i++) w[i] = A[i][i];
 }
 
-struct fuse_req {   // non-null: produce the spectral indices (+ normalised bands) in the projection pass
+struct fuse_req {   // non-null: produce the spectral indices (+ normalised bands, + the quantised texture band) in the projection pass
     float *const *d_idx;
     float *const *d_norm;
     const float *evi_coef;
+    uint8_t *d_q;
+    float q_lo, q_hi, q_mult;
 };
 static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
                     const float *center, const double *scale, int n_components, float *const *d_out, float *components,
@@ -505,8 +518,8 @@ extern "C" int rsseg_pca_fit_transform_ext_u8(rsseg_ctx *ctx, const uint8_t *con
 
 static int indices_pca_entry(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
                              const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
-                             float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components, float *explained_variance_ratio,
-                             float *mean, float *explained_variance)
+                             float *const *d_idx, float *const *d_norm, float *const *d_pc, uint8_t *d_q, float q_lo, float q_hi, float q_mult,
+                             float *components, float *explained_variance_ratio, float *mean, float *explained_variance)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
     if (nb < 5) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: the indices need bands 0..4 (blue, green, red, nir, swir1)");
@@ -516,27 +529,28 @@ static int indices_pca_entry(rsseg_ctx *ctx, const void *const *d_bands, bool u8
         if (d_idx[j] && ((uintptr_t)d_idx[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: index plane %d unaligned", j);
     for (int j = 0; j < 5; j++)
         if (d_norm && d_norm[j] && ((uintptr_t)d_norm[j] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: norm plane %d unaligned", j);
-    const fuse_req fr = {d_idx, d_norm, evi_coef};
+    if (d_q && ((uintptr_t)d_q & 3)) return rs_fail(ctx, RSSEG_ERR_INVALID, "indices_pca: quantised plane unaligned");
+    const fuse_req fr = {d_idx, d_norm, evi_coef, d_q, q_lo, q_hi, q_mult};
     return pca_core(ctx, d_bands, u8, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, d_pc, components, explained_variance_ratio, mean,
                     explained_variance, &fr);
 }
 
 extern "C" int rsseg_indices_pca_f32(rsseg_ctx *ctx, const float *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
                                      const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
-                                     float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
-                                     float *explained_variance_ratio, float *mean, float *explained_variance)
+                                     float *const *d_idx, float *const *d_norm, float *const *d_pc, uint8_t *d_q, float q_lo, float q_hi,
+                                     float q_mult, float *components, float *explained_variance_ratio, float *mean, float *explained_variance)
 {
     return indices_pca_entry(ctx, (const void *const *)d_bands, false, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, evi_coef, d_idx, d_norm,
-                             d_pc, components, explained_variance_ratio, mean, explained_variance);
+                             d_pc, d_q, q_lo, q_hi, q_mult, components, explained_variance_ratio, mean, explained_variance);
 }
 
 extern "C" int rsseg_indices_pca_u8(rsseg_ctx *ctx, const uint8_t *const *d_bands, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n,
                                     const float *lohi, const float *center, const double *scale, int n_components, const float *evi_coef,
-                                    float *const *d_idx, float *const *d_norm, float *const *d_pc, float *components,
-                                    float *explained_variance_ratio, float *mean, float *explained_variance)
+                                    float *const *d_idx, float *const *d_norm, float *const *d_pc, uint8_t *d_q, float q_lo, float q_hi,
+                                    float q_mult, float *components, float *explained_variance_ratio, float *mean, float *explained_variance)
 {
     return indices_pca_entry(ctx, (const void *const *)d_bands, true, nb, n_local, fit_off, fit_n, lohi, center, scale, n_components, evi_coef, d_idx, d_norm,
-                             d_pc, components, explained_variance_ratio, mean, explained_variance);
+                             d_pc, d_q, q_lo, q_hi, q_mult, components, explained_variance_ratio, mean, explained_variance);
 }
 
 static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb, int64_t n_local, int64_t fit_off, int64_t fit_n, const float *lohi,
@@ -748,6 +762,11 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
         fz.evi.C1 = fuse->evi_coef ? fuse->evi_coef[1] : 6.0f;
         fz.evi.C2 = fuse->evi_coef ? fuse->evi_coef[2] : 7.5f;
         fz.evi.G = fuse->evi_coef ? fuse->evi_coef[3] : 2.5f;
+        fz.q = fuse->d_q;
+        fz.q_lo = fuse->q_lo;
+        fz.q_hi = fuse->q_hi;
+        fz.q_den = norm_den(fuse->q_lo, fuse->q_hi);
+        fz.q_mult = fuse->q_mult;
         RSCHK(mm_begin(ctx, 7 + n_components));
         {
             prof_scope ps(ctx, "indices_project");

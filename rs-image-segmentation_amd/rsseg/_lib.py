@@ -62,11 +62,11 @@ SIGNATURES = {
                                               _int, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                               C.POINTER(C.c_float)]),
     "rsseg_indices_pca_f32": (_int, [_vp, _PP, _int, _i64, _i64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double), _int,
-                                     C.POINTER(C.c_float), _PP, _PP, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                     C.POINTER(C.c_float)]),
+                                     C.POINTER(C.c_float), _PP, _PP, _PP, _vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rsseg_indices_pca_u8": (_int, [_vp, _PP, _int, _i64, _i64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_double), _int,
-                                    C.POINTER(C.c_float), _PP, _PP, _PP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                    C.POINTER(C.c_float)]),
+                                    C.POINTER(C.c_float), _PP, _PP, _PP, _vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rsseg_normalize_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
     "rsseg_spectral_indices_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP]),
     "rsseg_spectral_indices_evi_f32": (_int, [_vp, _PP, _i64, C.POINTER(C.c_float), _PP, _PP, C.POINTER(C.c_float)]),

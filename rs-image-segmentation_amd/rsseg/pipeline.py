@@ -111,13 +111,13 @@ def pca(ctx: Context, norm_bands: Sequence, n_components: Optional[int] = None, 
 
 
 def indices_and_pca(ctx: Context, bands: Sequence, qb: Sequence[dict], lohi: np.ndarray, n_components: Optional[int], want_norm=(False,) * 5,
-                    fit: Optional[Tuple[int, int]] = None):
+                    fit: Optional[Tuple[int, int]] = None, quantize=None):
     """The seven indices and perform_pca of the same raw bands through the fused entry point (one Gram pass + ONE pass that
     writes indices, wanted normalised bands and components): (idx dict, norms, pcs, ratio, model)."""
     nc = len(bands) if n_components is None else n_components
     center = np.array([q["center"] for q in qb], np.float32)
     scale = np.array([q["scale"] for q in qb], np.float64)
-    idx, norms, pcs, comp, ratio, mean, ev = ctx.indices_pca(list(bands), lohi, center, scale, nc, want_norm=want_norm, fit=fit)
+    idx, norms, pcs, comp, ratio, mean, ev = ctx.indices_pca(list(bands), lohi, center, scale, nc, want_norm=want_norm, fit=fit, quantize=quantize)
     return dict(zip(INDEX_NAMES, idx)), norms, pcs, ratio, dict(components=comp, mean=mean, explained_variance=ev, center=center, scale=scale)
 
 
@@ -128,10 +128,13 @@ def renormalize(ctx: Context, plane, n_global: Optional[int] = None):
     return ctx.normalize(plane, float(lo), float(hi))
 
 
-def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size=21, step_size=21, upsample=True, renorm=None):
+def glcm_features(ctx: Context, nir_norm, H: int, W: int, levels=32, window_size=21, step_size=21, upsample=True, renorm=None, q=None):
     """calculate_glcm_features (indices.py:248-318) on an already re-normalised band, or — renorm=(lo, hi) — on the band
-    as the function receives it, re-normalised with its percentiles and quantised in one pass."""
-    if renorm is None:
+    as the function receives it, re-normalised with its percentiles and quantised in one pass, or — q — on the already
+    quantised uint8 plane (the fused index / PCA pass can write it)."""
+    if q is not None:
+        pass
+    elif renorm is None:
         q = ctx.quantize_u8(nir_norm, float(levels - 1))
     else:
         q = ctx.normalize_quantize_u8(nir_norm, float(renorm[0]), float(renorm[1]), float(levels - 1))
@@ -265,13 +268,15 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
         lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
         fused = all(q["center"] is not None for q in qb)
         want = tuple(i == NIR for i in range(5)) if fused else (True,) * 5
-        if fused:   # indices + PCA straight from the RAW bands: one Gram pass, one pass that writes indices, normalised NIR and components
-            idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca, want_norm=want)
+        if fused:   # indices + PCA straight from the RAW bands: one Gram pass, one pass that writes the indices, the components and the
+            # quantised texture band (the normalised NIR band itself is not needed by anything else in this configuration)
             lo2, hi2 = qb[NIR]["lo2"], qb[NIR]["hi2"]
+            idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca, quantize=(lo2, hi2, 31.0))
+            glcm, _ = glcm_features(ctx, None, H, W, 32, glcm_window, glcm_step, q=ctx.last_quantized)
         else:
             idx, norms = spectral_indices(ctx, bands, lohi, want_norm=want)
             lo2, hi2 = band_percentiles(ctx, norms[NIR], (2, 98), n_global)
-        glcm, _ = glcm_features(ctx, norms[NIR], H, W, 32, glcm_window, glcm_step, renorm=(lo2, hi2))
+            glcm, _ = glcm_features(ctx, norms[NIR], H, W, 32, glcm_window, glcm_step, renorm=(lo2, hi2))
         if fused:
             pass
         else:  # a band with NaNs: separate selects on the normalised planes

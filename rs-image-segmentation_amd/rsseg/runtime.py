@@ -399,10 +399,13 @@ class Context:
         return outs, comp, ratio, mean, ev
 
     def indices_pca(self, bands: Sequence, lohi: np.ndarray, center: Optional[np.ndarray], scale: Optional[np.ndarray], n_components: int,
-                    want_norm: Sequence[bool] = (False,) * 5, fit: Optional[Tuple[int, int]] = None, evi_coef: Optional[Sequence[float]] = None):
+                    want_norm: Sequence[bool] = (False,) * 5, fit: Optional[Tuple[int, int]] = None, evi_coef: Optional[Sequence[float]] = None,
+                    quantize: Optional[Tuple[float, float, float]] = None):
         """The seven spectral indices and the PCA of the same RAW bands with one pass less than spectral_indices +
         pca_fit_transform (rsseg_indices_pca_*): returns (index planes [7], normalised bands [5] (None where not wanted),
-        component planes, components, ratio, mean, explained_variance) — the same bits as the two separate calls."""
+        component planes, components, ratio, mean, explained_variance) — the same bits as the two separate calls.
+        quantize=(lo2, hi2, mult): additionally the uint8 plane normalize_quantize_u8(normalised NIR, lo2, hi2, mult) — the
+        texture chain's input — left in `self.last_quantized`."""
         torch = _torch()
         nb, n = len(bands), bands[0].numel()
         idx = [self.empty(n, torch.float32) for _ in range(7)]
@@ -425,9 +428,13 @@ class Context:
             raise ValueError("indices_pca: uint8 and float32 bands cannot be mixed")
         f0, fn_ = (0, n) if fit is None else (int(fit[0]), int(fit[1]))
         fn = self.lib.rsseg_indices_pca_u8 if all(u8) else self.lib.rsseg_indices_pca_f32
+        q = self.empty(n, torch.uint8) if quantize is not None else None
+        qlo, qhi, qm = (0.0, 1.0, 1.0) if quantize is None else [float(v) for v in quantize]
         self._chk(fn(self.h, self._pp(bands), nb, n, f0, fn_, lh.ctypes.data_as(fp), cptr, sptr, n_components, ec, self._pp(idx), self._pp(norms),
-                     self._pp(pcs), comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp), mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
+                     self._pp(pcs), None if q is None else C.c_void_p(q.data_ptr()), C.c_float(qlo), C.c_float(qhi), C.c_float(qm),
+                     comp.ctypes.data_as(fp), ratio.ctypes.data_as(fp), mean.ctypes.data_as(fp), ev.ctypes.data_as(fp)))
         self._tag_minmax(idx + pcs)
+        self.last_quantized = q      # the uint8 texture-chain input of this call (None unless `quantize` was given)
         return idx, norms, pcs, comp, ratio, mean, ev
 
     # ---- K4..K8 --------------------------------------------------------------------------------

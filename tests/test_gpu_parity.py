@@ -1048,8 +1048,12 @@ def test_fused_indices_pca_equals_the_two_separate_calls(ctx, oracle, n, u8):
             tags_s = [t._rsseg_minmax for t in idx_s]
             pc_s, comp_s, ratio_s, mean_s, ev_s = ctx.pca_fit_transform(d, center, scale, nc, lohi, fit=fit)
             tags_s += [t._rsseg_minmax for t in pc_s]
-            idx_f, norm_f, pc_f, comp_f, ratio_f, mean_f, ev_f = ctx.indices_pca(d, lohi, center, scale, nc, want_norm=(True,) * 5, fit=fit, evi_coef=evi)
+            lo2, hi2 = float(qb[3]["lo2"]), float(qb[3]["hi2"])
+            idx_f, norm_f, pc_f, comp_f, ratio_f, mean_f, ev_f = ctx.indices_pca(d, lohi, center, scale, nc, want_norm=(True,) * 5, fit=fit, evi_coef=evi,
+                                                                                 quantize=(lo2, hi2, 31.0))
             tags_f = [t._rsseg_minmax for t in idx_f + pc_f]
+            # the texture chain's input written by the same pass == the separate re-normalise + truncate kernel on the normalised NIR band
+            assert torch.equal(ctx.last_quantized, ctx.normalize_quantize_u8(norm_s[3], lo2, hi2, 31.0))
             for a, b in zip(idx_s + norm_s + pc_s, idx_f + norm_f + pc_f):
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32))
             assert np.array_equal(comp_s, comp_f) and np.array_equal(ratio_s, ratio_f) and np.array_equal(mean_s, mean_f) and np.array_equal(ev_s, ev_f)
