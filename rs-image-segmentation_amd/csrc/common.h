@@ -199,6 +199,20 @@ __device__ __forceinline__ void mm_commit_wg(uint32_t *slot, float mn, float mx)
     __syncthreads();
 }
 
+// streaming (read-once) 16-byte loads: non-temporal, so that 7-30 GB of planes per pass do not push the small tables and the
+// other streams' lines out of the caches
+typedef float rs_f4v __attribute__((ext_vector_type(4)));
+typedef unsigned int rs_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream_f4(const void *plane, int64_t i)
+{
+    const rs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const rs_f4v *>(plane) + i);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint32_t ld_stream_u32(const void *plane, int64_t i)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(plane) + i);
+}
+
 // ---- the seven spectral indices of one pixel (indices.py:62-69, 86-93, 109-112, 128-135, 150-156, 171-177, 194-201) ------------
 // shared by k2_indices and the fused index + PCA-projection kernel of k3_pca.hip; one IEEE float32 operation per NumPy operation
 __device__ __forceinline__ float clip11(float v)

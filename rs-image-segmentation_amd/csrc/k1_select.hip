@@ -128,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
             }
             float4 v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; u++) v[u] = x4[i + u * stride];
+            for (int u = 0; u < UNR; u++) v[u] = ld_stream_f4(x, i + u * stride);
 #pragma unroll
             for (int u = 0; u < UNR; u++) { handle(v[u].x); handle(v[u].y); handle(v[u].z); handle(v[u].w); }
         }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
         if (U8) {
             uint32_t w[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) w[j] = reinterpret_cast<const uint32_t *>(a.band[j])[i];
+            for (int j = 0; j < 5; j++) w[j] = ld_stream_u32(a.band[j], i);
 #pragma unroll
             for (int j = 0; j < 5; j++)
 #pragma unroll
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_indices(k2_args a, int64_t n, u
         } else {
             float4 b[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) b[j] = reinterpret_cast<const float4 *>(a.band[j])[i];
+            for (int j = 0; j < 5; j++) b[j] = ld_stream_f4(a.band[j], i);
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const float v[4] = {b[j].x, b[j].y, b[j].z, b[j].w};

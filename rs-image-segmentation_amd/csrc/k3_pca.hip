@@ -106,7 +106,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         if (U8) {
             uint32_t w[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) w[b] = ld_stream_u32(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 p0[b] = lut[b * 256 + (w[b] & 255u)];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         } else {
             float4 v[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) v[b] = ld_stream_f4(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
         }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
         if (U8) {
             uint32_t w[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) w[b] = ld_stream_u32(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_project(pca_args a, proj_args 
         } else {
             float4 v[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) v[b] = ld_stream_f4(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 x[0][b] = pca_x(a, b, v[b].x);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
         if (U8) {
             uint32_t w[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) w[b] = reinterpret_cast<const uint32_t *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) w[b] = ld_stream_u32(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
         } else {
             float4 v[NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) v[b] = reinterpret_cast<const float4 *>(a.band[b])[i];
+            for (int b = 0; b < NB; b++) v[b] = ld_stream_f4(a.band[b], i);
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const float vv[4] = {v[b].x, v[b].y, v[b].z, v[b].w};
