@@ -603,7 +603,7 @@ def pcie_inclusive(torch, device, ctx, bands, step, n_global):
     """The second figure SURVEY.md §8d asks for, each as ONE measured pass (wall clock around upload -> step -> download,
     transfers not overlapped with compute): (a) the 7 bands as float32 from pinned host memory, int32 / int64 labels back;
     (b) the bands as the 8-bit digital numbers they are (the TM tiles the reference reads are uint8) through
-    Context.upload_f32 — one byte per pixel over PCIe, widened on the device — and uint8 class ids back.
+    Context.upload_band — one byte per pixel over PCIe, one byte per pixel in HBM (the kernels read 8-bit planes) — and uint8 class ids back.
     Never the bench `value`."""
     try:
         host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in bands]

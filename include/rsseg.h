@@ -210,6 +210,9 @@ int rsseg_normalize_quantize_u8(rsseg_ctx *ctx, const float *d_x, int64_t n, flo
 /* uint8 plane -> float32 of (uint8 / 255.0 in float64): the value sklearn sees for the morphological members
  * (features[...] = gradient / 255.0, indices.py:436-440; float32 cast sklearn/ensemble/_forest.py:640). */
 int rsseg_u8_to_unit_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out);
+/* uint8 plane -> float32 plane, exact: band.astype(np.float32) of an 8-bit raster (scripts/2_feature_extraction.py:156), for the
+ * entry points that have no 8-bit form. */
+int rsseg_u8_to_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out);
 /* cv2.resize(src, (dw, dh), interpolation=INTER_LINEAR) for float32 (indices.py:308). */
 int rsseg_resize_bilinear_f32(rsseg_ctx *ctx, const float *d_src, int sh, int sw, float *d_dst, int dh, int dw);
 /* Row-striped form for sharded rasters: d_src holds rows [src_row0, src_row0 + sh_local) of a source sh rows tall,

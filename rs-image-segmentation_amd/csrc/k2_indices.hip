@@ -157,6 +157,18 @@ __global__ __launch_bounds__(K2_THREADS) void k2_u8_unit(const uint8_t *__restri
         y[i] = (float)((double)q[i] / 255.0);
 }
 
+__global__ __launch_bounds__(K2_THREADS) void k2_u8_widen(const uint8_t *__restrict__ q, float *__restrict__ y, int64_t n)
+{
+    // .astype(np.float32) of an 8-bit band (scripts/2_feature_extraction.py:156): exact
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * K2_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * K2_THREADS) {
+        const uint32_t w = ld_stream_u32(q, i);
+        reinterpret_cast<float4 *>(y)[i] = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+    }
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * K2_THREADS + threadIdx.x;
+    if (t < n) y[t] = (float)q[t];
+}
+
 static int stream_grid(int64_t n4)
 {
     return (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n4, K2_THREADS)));
@@ -266,6 +278,20 @@ extern "C" int rsseg_normalize_quantize_u8(rsseg_ctx *ctx, const float *d_x, int
         prof_scope ps(ctx, "quantize");
         hipLaunchKernelGGL(k2_quantize<true>, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_x, d_q, n, mult, lo, hi,
                            norm_den(lo, hi));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return stream_sync(ctx);
+}
+
+extern "C" int rsseg_u8_to_f32(rsseg_ctx *ctx, const uint8_t *d_q, int64_t n, float *d_out)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!d_q || !d_out || n < 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "u8_to_f32: bad arguments");
+    if (((uintptr_t)d_q & 3) || ((uintptr_t)d_out & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "u8_to_f32: unaligned plane");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+        prof_scope ps(ctx, "quantize");
+        hipLaunchKernelGGL(k2_u8_widen, dim3(stream_grid(n >> 2)), dim3(K2_THREADS), 0, ctx->stream, d_q, d_out, n);
     }
     HIPCHK(ctx, hipGetLastError());
     return stream_sync(ctx);

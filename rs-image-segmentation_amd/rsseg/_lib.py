@@ -83,6 +83,7 @@ SIGNATURES = {
     "rsseg_glcm_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _PP]),
     "rsseg_quantize_u8": (_int, [_vp, _vp, _i64, C.c_float, _vp]),
     "rsseg_u8_to_unit_f32": (_int, [_vp, _vp, _i64, _vp]),
+    "rsseg_u8_to_f32": (_int, [_vp, _vp, _i64, _vp]),
     "rsseg_resize_bilinear_f32": (_int, [_vp, _vp, _int, _int, _vp, _int, _int]),
     "rsseg_resize_bilinear_rows_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _int, _int, _int]),
     "rsseg_resize_bilinear_rows_multi_f32": (_int, [_vp, _PP, _int, _int, _int, _int, _int, _PP, _int, _int, _int, _int]),

@@ -200,11 +200,20 @@ class Context:
         torch = _torch()
         a = np.ascontiguousarray(a).reshape(-1)
         if a.dtype == np.uint8:
-            # the widening is a device kernel: it runs on THIS context's stream, where the library's kernels that read
-            # the plane are enqueued (a context may own a side stream that is not torch's current stream)
+            # widened by the library's own kernel, on THIS context's stream (where the kernels that read the plane are enqueued)
             with torch.cuda.stream(self.torch_stream):
-                return torch.from_numpy(a).to(self.device).to(torch.float32)
+                q = torch.from_numpy(a).to(self.device)
+            return self.widen_u8(q)
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def widen_u8(self, q):
+        """uint8 plane -> float32 plane (exact), rsseg_u8_to_f32."""
+        torch = _torch()
+        out = self.empty(q.numel(), torch.float32)
+        if getattr(self, "_async", False):
+            self._keep.append(q)
+        self._chk(self.lib.rsseg_u8_to_f32(self.h, C.c_void_p(q.data_ptr()), q.numel(), C.c_void_p(out.data_ptr())))
+        return out
 
     def upload_band(self, a: np.ndarray):
         """A band as a flat device plane in the narrowest form the kernels take: an 8-bit raster STAYS uint8 (order
@@ -304,10 +313,7 @@ class Context:
     def normalize(self, plane, lo: float, hi: float, out=None):
         torch = _torch()
         if self._is_u8(plane):   # only the striped / NaN side paths normalise a raw band on its own: widen it first
-            with torch.cuda.stream(self.torch_stream):
-                plane = plane.to(torch.float32)
-            if getattr(self, "_async", False):
-                self._keep.append(plane)
+            plane = self.widen_u8(plane)
         out = self.empty(plane.numel(), plane.dtype) if out is None else out
         self._chk(self.lib.rsseg_normalize_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo),
                                                C.c_float(hi), C.c_void_p(out.data_ptr())))
