@@ -1795,7 +1795,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     planes_t pl;
     memset(&pl, 0, sizeof(pl));
     for (int f = 0; f < F; f++) {
-        if (!d_planes[f] || ((uintptr_t)d_planes[f] & 15)) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: plane %d null or not 16-byte aligned", f);
+        // a rank without pixels (n_local == 0) may pass anything, also NULL: its planes are never read
+        if (n > 0 && (!d_planes[f] || ((uintptr_t)d_planes[f] & 15))) return rs_fail(ctx, RSSEG_ERR_INVALID, "kmeans: plane %d null or not 16-byte aligned", f);
         pl.p[f] = d_planes[f];
     }
 

@@ -290,6 +290,53 @@ def test_many_stripes_in_threads_equal_single_gpu(ctx, oracle, H, W, world):
             assert np.array_equal(p, want19[i][a:b], equal_nan=True), (r, i)
 
 
+@pytest.mark.parametrize("F,k,dt,splits", [(40, 5, np.float64, (0, 7001, 7001, 20011)),      # feature-blocked kernels; rank 1 holds NO pixels
+                                            (15, 8, np.float32, (0, 16384 * 3 + 5, 16384 * 3 + 9, 70001)),   # a 4-pixel rank
+                                            (2, 11, np.float32, (0, 30, 64, 97))])           # duplicate-heavy (seed 22 of the relocation test): clusters run empty
+def test_kmeans_entry_point_sharded_over_thread_ranks(ctx, oracle, F, k, dt, splits):
+    """rsseg_kmeans_fit_predict itself on consecutive slices of the pixel list, one context per slice (threads of this
+    process): the device-resident state, the stream-ordered collectives between the control kernels, a rank without
+    pixels, a rank smaller than one chunk, the feature-blocked kernels (F = 40) and the empty-cluster hand-over to the
+    host path, against the single-context run and the oracle: seeds, iteration count, relocations and labels."""
+    from rsseg.runtime import Context
+    rng = np.random.default_rng(F * 100 + k)
+    n = splits[-1]
+    if F == 2:   # the data of test_kmeans_empty_cluster_relocation[22]: 97 points, 2 features, 11 clusters, 2 relocations
+        rng = np.random.default_rng(22)
+        n_, F_, k_ = int(rng.integers(20, 120)), int(rng.integers(1, 4)), int(rng.integers(6, 14))
+        assert (n_, F_, k_) == (n, F, k)
+        X = rng.random((n, F)).astype(np.float32)
+        X = (np.round(X * rng.integers(2, 6)) / 4.0).astype(dt)
+    else:
+        cent = rng.random((k + 2, F))
+        X = (cent[rng.integers(0, k + 2, n)] + rng.normal(0, 0.07, (n, F))).astype(dt)
+    planes = [np.ascontiguousarray(X[:, f]) for f in range(F)]
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    if F == 2:
+        assert info["relocated"] > 0
+    labels, meta = ctx.kmeans_fit_predict([ctx.to_device(p) for p in planes], k)
+    assert np.array_equal(labels.cpu().numpy(), want) and meta["n_iter"] == info["n_iter"]
+    world = len(splits) - 1
+    tw = _ThreadWorld(world)
+    out = [None] * world
+
+    def rank_main(r):
+        c = Context(0, use_dist=False)
+        c.install_comm_hook(r, world, tw.hook(r))
+        a, b = splits[r], splits[r + 1]
+        d = [c.to_device(p[a:b].copy()) for p in planes]
+        lab, m = c.kmeans_fit_predict(d, k)
+        out[r] = (lab.cpu().numpy(), m["n_iter"], m["relocated"], m["init_indices"].copy())
+        c.close()
+
+    tw.run(rank_main)
+    for r in range(world):
+        lab, n_iter, reloc, seeds = out[r]
+        assert n_iter == info["n_iter"] and reloc == info["relocated"], r
+        assert np.array_equal(seeds, info["init_indices"]), r
+        assert np.array_equal(lab, want[splits[r]:splits[r + 1]]), r
+
+
 def test_full_size_eight_stripes_in_threads_equal_single_gpu(ctx):
     """BASELINE configs[3] at its real size: the 16384 x 16384 x 7 raster split into 8 stripes of 2048 rows (what
     `bench.py --gpus 8` gives every GPU), each stripe a thread with its own context on this one GPU.  Labels, iteration
