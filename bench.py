@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="c3, N = 1: GLCM chain on a second HIP stream (profiles/r01_overlap_note.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rccl-single", action="store_true", help="N = 1: a one-rank RCCL group with the all-reduce hook installed, so that every collective of a step (identity reductions) goes through torch.distributed / RCCL on this GPU")
     ap.add_argument("--launch-selftest", action="store_true", help="no GPU: every rank joins a gloo rendezvous on the CPU and rank 0 prints one line")
     args = ap.parse_args()
 
@@ -298,6 +299,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.rccl_single and world == 1:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            free_port = s_.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -306,7 +315,7 @@ def main():
             dist.init_process_group(args.backend)
     from rsseg import pipeline as P
     from rsseg.runtime import Context
-    ctx = Context(local)
+    ctx = Context(local, force_comm=args.rccl_single and world == 1)
 
     cfg = args.config
     H = W = args.size or (4096 if cfg == "c2" else 16384)
@@ -524,14 +533,14 @@ def main():
                        "ms_kpp_per_step": round(fams["kpp"][0] / args.steps, 2) if "kpp" in fams else None,
                        "data_kind": args.data,
                        "parallelism": (f"one raster row-striped x{world}, {'RCCL' if args.backend == 'nccl' else args.backend} all-reduce of histograms / PCA sums / KMeans partials / Sobel max"
-                                       if world > 1 else "single GPU"),
+                                       if world > 1 else ("single GPU, every collective through a one-rank RCCL group" if args.rccl_single else "single GPU")),
                        "host_syncs_per_step": round(host_syncs / args.steps, 1),
                        "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3),
                        **extras},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

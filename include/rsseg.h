@@ -81,7 +81,9 @@ int rsseg_ctx_last_minmax(rsseg_ctx *ctx, int plane, double *mn, double *mx);
  * Used to run the VALU-bound GLCM on a second stream beside the HBM-bound passes (rsseg/pipeline.py). */
 int rsseg_ctx_set_async(rsseg_ctx *ctx, int on);
 int rsseg_ctx_sync(rsseg_ctx *ctx);
-/* d_comm: device buffer of comm_bytes (>= 1 MiB) owned by the caller, visible to the hook. */
+/* d_comm: device buffer of comm_bytes (>= 1 MiB) owned by the caller, visible to the hook.  The hook is called whenever one is
+ * installed together with a buffer — also with world == 1, where the reduction is the identity: that is how a one-GPU box
+ * runs every collective of a step through RCCL.  fn == NULL with world == 1 removes it. */
 int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn fn, void *user,
                        void *d_comm, size_t comm_bytes);
 

@@ -94,9 +94,10 @@ extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_all
     ctx->comm_user = user;
     ctx->d_comm = (char *)d_comm;
     ctx->comm_bytes = comm_bytes;
+    ctx->comm_on = world > 1 || (fn && d_comm && comm_bytes >= (1u << 20));
     if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
     ctx->h_comm = nullptr;
-    if (world > 1) {
+    if (ctx->comm_on) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         if (hipHostMalloc((void **)&ctx->h_comm, comm_bytes, hipHostMallocDefault) != hipSuccess)
             return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipHostMalloc(%zu) for the communication staging buffer failed", comm_bytes);
@@ -156,7 +157,7 @@ extern "C" int rsseg_ctx_sync(rsseg_ctx *ctx)
 
 int comm_allreduce_host(rsseg_ctx *ctx, void *host, int64_t count, int dtype, int op)
 {
-    if (ctx->world <= 1) return RSSEG_OK;
+    if (!ctx->comm_on) return RSSEG_OK;
     const size_t esz = dtype == RSSEG_F32 ? 4 : 8;
     const size_t bytes = esz * (size_t)count;
     if (bytes > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "comm buffer too small (%zu > %zu)", bytes, ctx->comm_bytes);

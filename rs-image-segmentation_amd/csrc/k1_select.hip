@@ -227,7 +227,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     unsigned long long *d_hist_all = (unsigned long long *)ctx->d_ws;
     uint32_t *d_pre_all = (uint32_t *)(ctx->d_ws + (size_t)P * hist_bytes);  // [P][64]
     long long *h_hist_all = (long long *)ctx->h_pin;
-    if (ctx->world > 1 && (size_t)P * hist_bytes > ctx->comm_bytes)
+    if (ctx->comm_on && (size_t)P * hist_bytes > ctx->comm_bytes)
         return rs_fail(ctx, RSSEG_ERR_COMM, "order_stats: %d planes may need a %zu-byte communication buffer", P, (size_t)P * hist_bytes);
 
     static bool attr_done[64] = {false};  // hipFuncSetAttribute is per device

@@ -1860,10 +1860,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     // values that cross ranks: in the communication buffer when world > 1 (the hook reduces them in place), else in the workspace
     const size_t x_need = sizeof(long long) * std::max<size_t>({(size_t)2 * M, (size_t)3 * F, (size_t)2 * F + 2 * (size_t)ctx->world,
                                                                 (size_t)2 * KPP_MAXL * RSSEG_MAX_RANKS + KPP_MAXL * (1 + RSSEG_MAX_FEATURES) + 64});
-    if (ctx->world > 1 && x_need > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small (%zu > %zu)", x_need, ctx->comm_bytes);
-    long long *d_x = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;
+    if (ctx->comm_on && x_need > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small (%zu > %zu)", x_need, ctx->comm_bytes);
+    long long *d_x = ctx->comm_on ? (long long *)ctx->d_comm : d_red;
     auto dev_allreduce = [&](int64_t byte_off, int64_t count, int dtype, int op) -> int {   // stream-ordered: no staging copy, no host synchronisation
-        if (ctx->world <= 1) return RSSEG_OK;
+        if (!ctx->comm_on) return RSSEG_OK;
         const auto t0c = std::chrono::steady_clock::now();
         const int rc = ctx->allreduce(ctx->comm_user, byte_off, count, dtype, op);
         if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce hook returned %d", rc);
@@ -2166,8 +2166,8 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     };
 
     // ---- device-resident loop: batches of speculatively enqueued iterations, one look at the state per batch ----
-    long long *d_sums = ctx->world > 1 ? (long long *)ctx->d_comm : d_red;   // where km_reduce_cols leaves the limb sums
-    if (ctx->world > 1 && sizeof(long long) * 2 * (size_t)M > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small");
+    long long *d_sums = ctx->comm_on ? (long long *)ctx->d_comm : d_red;   // where km_reduce_cols leaves the limb sums
+    if (ctx->comm_on && sizeof(long long) * 2 * (size_t)M > ctx->comm_bytes) return rs_fail(ctx, RSSEG_ERR_COMM, "kmeans: comm buffer too small");
     bool finished = false, host_mode = false;
     int batch = 4;
     km_state<T> *h_state = (km_state<T> *)ctx->h_pin;
@@ -2179,7 +2179,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             RSCHK(run_lloyd(true, true, false));
             hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_sums, (const int *)&d_lst->done, 1, 0);
             HIPCHK(ctx, hipGetLastError());
-            if (ctx->world > 1) {   // stream-ordered: no staging copy, no host synchronisation (include/rsseg.h, rsseg_allreduce_fn)
+            if (ctx->comm_on) {   // stream-ordered: no staging copy, no host synchronisation (include/rsseg.h, rsseg_allreduce_fn)
                 const auto t0c = std::chrono::steady_clock::now();
                 if (n <= 0) HIPCHK(ctx, hipMemsetAsync(d_sums, 0, sizeof(long long) * 2 * M, st));
                 const int rc = ctx->allreduce(ctx->comm_user, 0, 2 * (int64_t)M, RSSEG_I64, RSSEG_SUM);

@@ -72,8 +72,10 @@ class Context:
     """Owns an rsseg_ctx.  `group` (optional) is a torch.distributed process group: when its world
     size is > 1 the library's reductions go through RCCL (or gloo in CPU tests of the hook)."""
 
-    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None, stream=None):
-        """stream: a torch.cuda.Stream for this context (default: torch's current stream)."""
+    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None, stream=None, force_comm: bool = False):
+        """stream: a torch.cuda.Stream for this context (default: torch's current stream).
+        force_comm: install the all-reduce hook even when the group has ONE rank (identity reductions), so that every
+        collective of a step runs through the backend — the way to exercise the RCCL path on a one-GPU box."""
         torch = _torch()
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -96,7 +98,7 @@ class Context:
         import torch.distributed as dist
         if use_dist is None:
             use_dist = dist.is_available() and dist.is_initialized()
-        if use_dist and dist.get_world_size(group) > 1:
+        if use_dist and (dist.get_world_size(group) > 1 or force_comm):
             self._install_comm(group)
 
     # ---- communication hook ----------------------------------------------------------------

@@ -15,7 +15,11 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "rccl_single":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from rsseg import _lib as L
     from rsseg.runtime import make_allreduce_hook
     if mode == "hook_cpu":
@@ -98,6 +102,52 @@ def main():
         np.savez(os.path.join(outdir, f"out_{rank}.npz"), labels=labels.cpu().numpy(), r0=r0, r1=r1,
                  **{f"p{i}": p.cpu().numpy() for i, p in enumerate(planes)})
         ctx.close()
+    elif mode == "rccl_single":
+        # ONE rank, backend nccl (= RCCL), the hook installed all the same: every collective of the step is an identity
+        # reduction that really goes through torch.distributed / RCCL on this GPU, stream-ordered (no host wait in the
+        # hook).  (1) the hook alone: ordered after earlier work on the context's stream, visible to later work there;
+        # (2) config 3 and the 19-feature stack + forest through it, bit-identical to a context without a hook.
+        from rsseg import pipeline as P
+        from rsseg.runtime import Context
+        side = torch.cuda.Stream()
+        buf = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
+        hook = make_allreduce_hook(buf, None, side)
+        big = torch.zeros(1 << 26, dtype=torch.int64, device="cuda")
+        with torch.cuda.stream(side):
+            big.add_(3)                                         # ~1 ms of work in front of the writer
+            buf[:80].view(torch.int64).copy_(big[:10] * 5 + torch.arange(10, device="cuda"))
+        assert hook(None, 0, 10, L.I64, L.SUM) == 0             # no host wait in between
+        with torch.cuda.stream(side):
+            got = buf[:80].view(torch.int64) + 1
+        side.synchronize()
+        assert got.tolist() == [16 + i for i in range(10)], got.tolist()
+        data = np.load(os.path.join(outdir, "input.npz"))
+        bands = data["bands"]
+        H, W = bands.shape[1:]
+        res = []
+        for force in (False, True):
+            ctx = Context(0, use_dist=True, force_comm=force)
+            assert ctx.world == 1
+            ctx.prof_enable(True)
+            dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(bands.shape[0])]
+            labels, meta, planes = P.config3(ctx, dev, H, W, int(data["k"]))
+            st, _ = P.feature_stack19(ctx, dev, H, W)
+            forest = {k[7:]: data[k] for k in data.files if k.startswith("forest_")}
+            forest["n_features"] = int(forest["n_features"])
+            ctx.forest_load(forest)
+            fl = ctx.forest_predict(P.stack19_forest_planes(ctx, st))
+            _, calls = ctx.prof_get("allreduce")
+            res.append(dict(labels=labels.cpu().numpy(), centers=meta["centers"], n_iter=meta["n_iter"], init=meta["init_indices"],
+                            planes=[p.cpu().numpy() for p in planes], st=[p.cpu().numpy() for p in st], fl=fl.cpu().numpy(), calls=calls))
+            ctx.close()
+        a, b = res
+        assert a["calls"] == 0 and b["calls"] >= 20, (a["calls"], b["calls"])
+        assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["centers"], b["centers"])
+        assert a["n_iter"] == b["n_iter"] and np.array_equal(a["init"], b["init"])
+        for x, y in zip(a["planes"] + a["st"], b["planes"] + b["st"]):
+            assert np.array_equal(x, y, equal_nan=True)
+        assert np.array_equal(a["fl"], b["fl"])
+        open(os.path.join(outdir, "ok_rccl"), "w").write(str(b["calls"]))
     dist.destroy_process_group()
 
 

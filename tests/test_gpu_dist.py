@@ -103,6 +103,30 @@ def test_striped_config3_equals_single_gpu(ctx, oracle, tmp_path, world):
     assert np.array_equal(np.concatenate(got), want)
 
 
+def test_every_collective_through_a_one_rank_rccl_group(ctx, oracle, tmp_path):
+    """The RCCL branch of make_allreduce_hook on the hardware a one-GPU box has: a one-rank `nccl` group, the hook
+    installed all the same (Context(force_comm=True)), so that each collective of config 3 and of the 19-feature stack
+    is an identity reduction that goes through torch.distributed / RCCL, stream-ordered, without a host wait in the
+    hook.  Results equal those of a context without a hook bit for bit; the worker also checks the hook's ordering
+    against work queued on a side stream."""
+    from sklearn.ensemble import RandomForestClassifier
+    from rsseg import pipeline as P
+    from rsseg.forest import flatten_forest
+    H, W = 230, 200
+    bands = oracle.synthetic_raster(H, W)
+    dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(7)]
+    planes, _ = P.feature_stack19(ctx, dev, H, W)
+    X = np.stack([p.cpu().numpy() for p in P.stack19_forest_planes(ctx, planes)], 1)
+    rng = np.random.default_rng(6)
+    sel = rng.choice(H * W, 3000, replace=False)
+    y = ((np.arange(H)[:, None] // 16 + np.arange(W)[None, :] // 16) % 4).reshape(-1)[sel]
+    forest = flatten_forest(RandomForestClassifier(n_estimators=8, max_depth=8, random_state=2).fit(X[sel], y))
+    np.savez(tmp_path / "input.npz", bands=bands, k=6, **{f"forest_{k}": np.asarray(v) for k, v in forest.items()})
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), "rccl_single", "0", "1", _free_port(), str(tmp_path)])
+    _wait_all([p])
+    assert int(open(tmp_path / "ok_rccl").read()) >= 20
+
+
 @pytest.mark.parametrize("H,W,world", [(190, 136, 2), (190, 136, 3), (173, 150, 3)])
 def test_striped_stack19_and_forest_equal_single_gpu(ctx, oracle, tmp_path, H, W, world):
     """BASELINE config 5 sharded: every rank holds its stripe plus the halo rows of stack19_halo_rows (3 rows for the 7x7
