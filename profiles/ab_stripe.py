@@ -1,6 +1,7 @@
 """A/B of two builds of the library on one box: config 3 on an H x 16384 raster (what a rank of 16384/H computes)."""
 import sys, time, os
-sys.path.insert(0, "rs-image-segmentation_amd"); sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rs-image-segmentation_amd")); sys.path.insert(0, ROOT)
 from rsseg import _lib
 if len(sys.argv) > 2 and sys.argv[2] != "-":
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
