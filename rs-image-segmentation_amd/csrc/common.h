@@ -38,6 +38,7 @@ struct rsseg_ctx {
     char err[512] = {0};
     // communication
     int rank = 0, world = 1;
+    std::vector<std::pair<const void *, int64_t>> byte_valued;   // (plane, pixels) the last select saw hold only the integers 0..255 (a hint: users verify)
     bool comm_on = false;   // reductions go through the hook: world > 1, or a hook installed on a single rank (identity reduction; how a one-GPU box exercises the RCCL path)
     rsseg_allreduce_fn allreduce = nullptr;
     void *comm_user = nullptr;

@@ -218,6 +218,7 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
                             float *out_values, int64_t *n_nan_out)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->byte_valued.clear();
     // per plane: 8 words (NaN counter first) then up to RSSEG_MAX_RANKS tables of 2048 bins; only the tables a pass
     // uses travel to the host and through the all-reduce
     const size_t hist_elems = 8 + (size_t)RSSEG_MAX_RANKS * SEL_BINS;
@@ -287,6 +288,11 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
             for (int p = 0; p < P; p++) {
                 const long long *h_nanp = h_hist_all + (size_t)p * used, *h = h_nanp + 8;
                 const int64_t *rk = ranks + (size_t)p * nranks;
+                {   // a plane of 8-bit digital numbers (no NaN, nothing above 255): later passes over it may use 256-entry tables
+                    bool bytes = h_nanp[0] == 0;
+                    for (int b = 256; b < SEL_BINS && bytes; b++) bytes = h[b] == 0;
+                    if (bytes) ctx->byte_valued.emplace_back((const void *)d_planes[p], n_local);
+                }
                 int64_t n_global = h_nanp[0];
                 for (int b = 0; b < SEL_BINS; b++) n_global += h[b];
                 for (int r = 0; r < nranks; r++) {

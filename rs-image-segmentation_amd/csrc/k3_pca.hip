@@ -62,17 +62,28 @@ __host__ __device__ constexpr int pca_tri(int b, int c) { return PCA_MAXB + b * 
 // the float path applies per pixel (same bits): the two divisions per band and pixel become one LDS look-up.
 template <int NB, bool U8> __device__ __forceinline__ void pca_fill_lut(const pca_args &a, float *lut)
 {
-    if (U8) {
+    if (U8) {   // (the float32 try-pass of k3_gram passes U8 = true here: the same table)
         for (int i = threadIdx.x; i < NB * 256; i += PCA_THREADS) lut[i] = pca_x(a, i >> 8, (float)(i & 255));
         __syncthreads();
     }
 }
 
-template <int NB, bool U8>
+// FL (float32 planes, tried first when the select has just seen these planes hold only integers 0..255 — the reference's
+// preprocessed tiles are 8-bit digital numbers stored as float32): the table of the U8 form, indexed by the value; a value
+// that is not such an integer (or NaN) is counted in the partial table's spare slot and the host runs the general form.
+template <int NB, bool U8, bool FL = false>
 __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, long long *__restrict__ partial)
 {
-    __shared__ float lut[U8 ? NB * 256 : 1];
-    pca_fill_lut<NB, U8>(a, lut);
+    static_assert(!(U8 && FL), "FL is a form of the float32 kernel");
+    constexpr bool TAB = U8 || FL;
+    __shared__ float lut[TAB ? NB * 256 : 1];
+    pca_fill_lut<NB, TAB>(a, lut);
+    bool miss = false;
+    auto tab = [&](int b, float v) {   // FL: the table entry of an integer-valued v in [0, 255]
+        const int idx = (int)v;
+        miss = miss || !(v == (float)idx && (unsigned)idx < 256u);
+        return lut[b * 256 + (idx & 255)];
+    };
     // partial[blk][2 * PCA_NACC + 2]: the limb sums, then the number of threads that met a NaN (sklearn's PCA rejects
     // NaN input; a NaN's bit pattern in the integer sums would otherwise pass unnoticed), then padding
     bool bad = false;
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         float x[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            x[b] = U8 ? v[b] : pca_x(a, b, v[b]);
+            x[b] = TAB ? v[b] : pca_x(a, b, v[b]);
             bad = bad || x[b] != x[b];
         }
 #pragma unroll
@@ -119,7 +130,10 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
 #pragma unroll
             for (int b = 0; b < NB; b++) v[b] = ld_stream_f4(a.band[b], i);
 #pragma unroll
-            for (int b = 0; b < NB; b++) { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+            for (int b = 0; b < NB; b++) {
+                if (FL) { p0[b] = tab(b, v[b].x); p1[b] = tab(b, v[b].y); p2[b] = tab(b, v[b].z); p3[b] = tab(b, v[b].w); }
+                else { p0[b] = v[b].x; p1[b] = v[b].y; p2[b] = v[b].z; p3[b] = v[b].w; }
+            }
         }
         pixel(p0); pixel(p1); pixel(p2); pixel(p3);
     }
@@ -128,7 +142,8 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         float p[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++)
-            p[b] = U8 ? lut[b * 256 + reinterpret_cast<const uint8_t *>(a.band[b])[t]] : reinterpret_cast<const float *>(a.band[b])[t];
+            p[b] = U8 ? lut[b * 256 + reinterpret_cast<const uint8_t *>(a.band[b])[t]]
+                      : FL ? tab(b, reinterpret_cast<const float *>(a.band[b])[t]) : reinterpret_cast<const float *>(a.band[b])[t];
         pixel(p);
     }
     const unsigned long long bias = cnt * (unsigned long long)__double_as_longlong(FX_MAGIC);
@@ -146,12 +161,13 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
         if (lane_id() == 0) { sh[threadIdx.x >> 6][2 * i] = hi; sh[threadIdx.x >> 6][2 * i + 1] = lo; }
     }
     const int nbad = __syncthreads_count(bad);
+    const int nmiss = FL ? __syncthreads_count(miss) : 0;
     if (threadIdx.x < 2 * PCA_NACC)
         partial[(size_t)blockIdx.x * PCA_PSTRIDE + threadIdx.x] =
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
     if (threadIdx.x == 0) {
         partial[(size_t)blockIdx.x * PCA_PSTRIDE + 2 * PCA_NACC] = nbad;
-        partial[(size_t)blockIdx.x * PCA_PSTRIDE + 2 * PCA_NACC + 1] = 0;
+        partial[(size_t)blockIdx.x * PCA_PSTRIDE + 2 * PCA_NACC + 1] = nmiss;
     }
 }
 
@@ -430,6 +446,20 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
     }
 }
 
+// Column sums of the partial table (nblk rows of PCA_PSTRIDE long longs): the host gets ONE row (720 B) instead of the table
+// (1.5 MB at 2048 blocks) and a 90 x 2048 loop.  Limb sums stay far below 2^63 (hi < 2^37, lo < 2^40 per row, <= 2049 rows).
+__global__ __launch_bounds__(256) void k3_reduce_partials(const long long *__restrict__ partial, int nblk, long long *__restrict__ out)
+{
+    const int col = blockIdx.x;
+    long long s = 0;
+    for (int g = threadIdx.x; g < nblk; g += 256) s += partial[(size_t)g * PCA_PSTRIDE + col];
+    s = wave_sum(s);
+    __shared__ long long sh[4];
+    if (lane_id() == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[col] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // cyclic Jacobi for a small symmetric matrix (float64).  V columns = eigenvectors.
 static void jacobi_eigh(int n, double A[PCA_MAXB][PCA_MAXB], double V[PCA_MAXB][PCA_MAXB], double *w)
 {
@@ -646,43 +676,54 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
             pcount += (size_t)g * PCA_PSTRIDE;
         }
     }
-    RSCHK(ws_reserve(ctx, sizeof(long long) * std::max<size_t>(pcount, 1)));
-    RSCHK(pin_reserve(ctx, sizeof(long long) * std::max<size_t>(pcount, 1)));
-    long long *d_part = (long long *)ctx->d_ws;
-    for (int si = 0; si < nseg; si++) {
-        pca_args as = a;
-        for (int b = 0; b < nb; b++) as.band[b] = (const char *)a.band[b] + (size_t)segs[si].off * esz;
-        prof_scope ps(ctx, "gram");
-        switch (nb) {
+    RSCHK(ws_reserve(ctx, sizeof(long long) * (pcount + PCA_PSTRIDE)));
+    RSCHK(pin_reserve(ctx, sizeof(long long) * PCA_PSTRIDE));
+    long long *d_part = (long long *)ctx->d_ws, *d_tot = d_part + pcount;
+    // float32 planes the select has just seen to hold only the integers 0..255: the table form first (the kernel verifies every
+    // value, so a stale hint costs a pass, never a result)
+    bool try_tab = !u8 && a.normalise;
+    for (int b = 0; b < nb && try_tab; b++) {
+        bool hit = false;
+        for (const auto &h : ctx->byte_valued) hit = hit || (h.first == d_bands[b] && fit_off + fit_n <= h.second);
+        try_tab = hit;
+    }
+    auto run_gram = [&](bool tab) -> int {
+        for (int si = 0; si < nseg; si++) {
+            pca_args as = a;
+            for (int b = 0; b < nb; b++) as.band[b] = (const char *)a.band[b] + (size_t)segs[si].off * esz;
+            prof_scope ps(ctx, "gram");
+            switch (nb) {
 #define GRAM_GO(NBV)                                                                                                                          \
     case NBV:                                                                                                                                 \
         if (u8) hipLaunchKernelGGL((k3_gram<NBV, true>), dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff);  \
+        else if (tab) hipLaunchKernelGGL((k3_gram<NBV, false, true>), dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff);  \
         else hipLaunchKernelGGL((k3_gram<NBV, false>), dim3(segs[si].grid), dim3(PCA_THREADS), 0, ctx->stream, as, segs[si].n, d_part + segs[si].poff);   \
         break;
-            GRAM_GO(1) GRAM_GO(2) GRAM_GO(3) GRAM_GO(4) GRAM_GO(5) GRAM_GO(6) GRAM_GO(7) GRAM_GO(8)
+                GRAM_GO(1) GRAM_GO(2) GRAM_GO(3) GRAM_GO(4) GRAM_GO(5) GRAM_GO(6) GRAM_GO(7) GRAM_GO(8)
 #undef GRAM_GO
+            }
         }
-    }
-    HIPCHK(ctx, hipGetLastError());
-    if (pcount) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_part, sizeof(long long) * pcount, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, rs_sync(ctx));
-    }
+        HIPCHK(ctx, hipGetLastError());
+        if (pcount) {
+            hipLaunchKernelGGL(k3_reduce_partials, dim3(PCA_PSTRIDE), dim3(256), 0, ctx->stream, (const long long *)d_part, (int)(pcount / PCA_PSTRIDE), d_tot);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_tot, sizeof(long long) * PCA_PSTRIDE, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, rs_sync(ctx));
+        }
+        return RSSEG_OK;
+    };
+    RSCHK(run_gram(try_tab));
+    if (try_tab && pcount && ((const long long *)ctx->h_pin)[2 * PCA_NACC + 1] != 0) RSCHK(run_gram(false));   // some value was not an integer 0..255
     typedef __int128 i128;
     long long lim[2 * PCA_NACC + 2];
     {
         const long long *hp = (const long long *)ctx->h_pin;
-        const size_t nblk = pcount / PCA_PSTRIDE;
         for (int i = 0; i < PCA_NACC; i++) {
-            i128 s = 0;
-            for (size_t g = 0; g < nblk; g++) s += ((i128)hp[g * PCA_PSTRIDE + 2 * i] << 32) + (i128)hp[g * PCA_PSTRIDE + 2 * i + 1];
+            const i128 s = pcount ? ((i128)hp[2 * i] << 32) + (i128)hp[2 * i + 1] : (i128)0;
             lim[2 * i] = (long long)(s >> 32);
             lim[2 * i + 1] = (long long)(s & 0xffffffffLL);
         }
-        long long nbad = 0;
-        for (size_t g = 0; g < nblk; g++) nbad += hp[g * PCA_PSTRIDE + 2 * PCA_NACC];
         lim[2 * PCA_NACC] = fit_n;
-        lim[2 * PCA_NACC + 1] = nbad;
+        lim[2 * PCA_NACC + 1] = pcount ? hp[2 * PCA_NACC] : 0;   // (slot 2 * PCA_NACC + 1 of the table: the try-pass's misses, zero here)
     }
     RSCHK(comm_allreduce_host(ctx, lim, 2 * PCA_NACC + 2, RSSEG_I64, RSSEG_SUM));
     if (lim[2 * PCA_NACC + 1] != 0) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: Input X contains NaN.");

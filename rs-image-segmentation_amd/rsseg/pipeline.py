@@ -38,7 +38,7 @@ def band_quantile_bundles(ctx: Context, bands: Sequence, n_global: Optional[int]
     arithmetic, so the k-th smallest normalised value is f(k-th smallest raw value): the quantiles of the
     normalised band follow from the raw band's order statistics pushed through f on the host (same float32
     operations as the K2 kernel).  A band that holds NaNs falls back to separate selects."""
-    from .quantiles import median_plan, percentile_plan
+    from .quantiles import lerp_rows, median_plan, percentile_plan
     n = int(bands[0].numel()) if n_global is None else int(n_global)
     p2r, p2f = percentile_plan(n, 2, np.float32, True)
     p98r, p98f = percentile_plan(n, 98, np.float32, True)
@@ -52,19 +52,17 @@ def band_quantile_bundles(ctx: Context, bands: Sequence, n_global: Optional[int]
         vals_all, nan_all = ctx.order_stats_multi(group, [ranks] * len(group))
         # the host arithmetic of all planes of the group at once (elementwise NumPy operations on (P,) arrays give, value
         # for value, what the same operations give on one plane's scalars): the GPU idles while this runs
-        parts = [vals_all[:, cuts[i]:cuts[i + 1]] for i in range(4)]
-        lo, hi = p2f(parts[0]), p98f(parts[1])            # (P,) float32
-        den = hi - lo + 1e-10                            # float32, as in robust_normalize
-
-        def f(v):
-            return (np.clip(v, lo[:, None], hi[:, None]) - lo[:, None]) / den[:, None]
-
+        # Planes that hold NaNs take the separate path below; their rows here are computed and discarded.
         with np.errstate(invalid="ignore"):
-            center = mf(f(parts[2])).astype(np.float32)
-            q = qf(f(parts[3]))                          # (P, 2) float64
-            scale = (q[:, 1] - q[:, 0]).astype(np.float64)
+            lo, hi = lerp_rows(p2f, vals_all[:, cuts[0]:cuts[1]]), lerp_rows(p98f, vals_all[:, cuts[1]:cuts[2]])   # (P,) float32
+            den = hi - lo + 1e-10                            # float32, as in robust_normalize
+            lo_ = lo[:, None]
+            fa = (np.minimum(np.maximum(vals_all, lo_), hi[:, None]) - lo_) / den[:, None]    # f of every fetched value (np.clip's two steps)
+            center = mf(fa[:, cuts[2]:cuts[3]]).astype(np.float32)
+            q = lerp_rows(qf, fa[:, cuts[3]:cuts[4]])        # (P, 2) float64
+            scale = q[:, 1] - q[:, 0]
             scale = np.where(scale < 10 * np.finfo(np.float64).eps, np.float64(1.0), scale)
-            lo2, hi2 = p2f(f(parts[0])), p98f(f(parts[1]))
+            lo2, hi2 = lerp_rows(p2f, fa[:, cuts[0]:cuts[1]]), lerp_rows(p98f, fa[:, cuts[1]:cuts[2]])
         for i, (band, n_nan) in enumerate(zip(group, nan_all)):
             if n_nan > 0:
                 blo, bhi = band_percentiles(ctx, band, (2, 98), n_global)

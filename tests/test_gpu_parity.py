@@ -1062,6 +1062,73 @@ def test_fused_indices_pca_equals_the_two_separate_calls(ctx, oracle, n, u8):
         ctx.collect_minmax(False)
 
 
+@pytest.mark.parametrize("n", [4099, 300001])
+def test_gram_table_pass_for_byte_valued_float_planes(ctx, n):
+    """float32 planes that the select has just seen to hold only the integers 0..255 take the Gram pass with 256-entry
+    tables (k3_gram<NB, false, true>); the kernel verifies every value.  (1) the model equals the general kernel's bit for
+    bit (the hint is dropped by a select on some other plane); (2) a STALE hint — planes changed after the select — costs
+    a second pass, never a result; (3) so does a plane with values above 255 or a NaN."""
+    import torch
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(n)
+    raw = [np.clip(rng.normal(80 + 15 * b, 30, n), 0, 255).astype(np.uint8).astype(np.float32) for b in range(7)]
+    d = [ctx.to_device(b) for b in raw]
+    other = ctx.to_device(rng.random(1000).astype(np.float32))
+
+    def model(planes, hinted, fit=None):
+        qb = P.band_quantile_bundles(ctx, planes, n)               # leaves the hint for these planes
+        lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+        center = np.array([q["center"] for q in qb], np.float32)
+        scale = np.array([q["scale"] for q in qb], np.float64)
+        if not hinted:
+            ctx.order_stats(other, [0])                            # a select on another plane drops it
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        out = ctx.pca_fit_transform(planes, center, scale, 3, lohi, fit=fit)
+        _, launches = ctx.prof_get("gram")
+        ctx.prof_enable(False)
+        return out, launches, (lohi, center, scale)
+
+    for fit in (None, (5, n - 9)):
+        (pc_t, *m_t), l_t, _ = model(d, True, fit)
+        (pc_g, *m_g), l_g, _ = model(d, False, fit)
+        assert l_t == l_g                                          # one pass each (a head segment adds a launch to both)
+        for x, y in zip(m_t, m_g):
+            assert np.array_equal(x, y)
+        for x, y in zip(pc_t, pc_g):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    # stale hint: the planes change between the select and the PCA
+    qb = P.band_quantile_bundles(ctx, d, n)
+    lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
+    center = np.array([q["center"] for q in qb], np.float32)
+    scale = np.array([q["scale"] for q in qb], np.float64)
+    d[2].add_(torch.rand(n, device=d[2].device) * 0.5)
+    d[5][n // 2] = 300.0
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pc_s, *m_s = ctx.pca_fit_transform(d, center, scale, 3, lohi)
+    _, l_s = ctx.prof_get("gram")
+    ctx.prof_enable(False)
+    ctx.order_stats(other, [0])
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pc_r, *m_r = ctx.pca_fit_transform(d, center, scale, 3, lohi)
+    _, l_r = ctx.prof_get("gram")
+    ctx.prof_enable(False)
+    assert l_s == 2 * l_r                                          # the table pass, then the general one
+    for x, y in zip(m_s, m_r):
+        assert np.array_equal(x, y)
+    for x, y in zip(pc_s, pc_r):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    # a NaN under a stale hint is still reported
+    P.band_quantile_bundles(ctx, [ctx.to_device(b) for b in raw], n)
+    d2 = [ctx.to_device(b) for b in raw]
+    P.band_quantile_bundles(ctx, d2, n)
+    d2[1][7] = float("nan")
+    with pytest.raises(Exception, match="NaN"):
+        ctx.pca_fit_transform(d2, center, scale, 3, lohi)
+
+
 def test_config3_on_uint8_bands_equals_float32_bands(ctx, oracle):
     """The whole config-3 pipeline fed with uint8 band planes: labels, seeds, iteration count and feature planes equal
     those of the float32 planes."""

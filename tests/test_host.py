@@ -64,6 +64,30 @@ def test_robust_scaler_plans_equal_numpy(n):
     assert got.dtype == want.dtype and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 101, 9216, 360000, 33554432])
+def test_lerp_rows_equals_plan_finish(n):
+    """The few-call finish of several planes (pipeline.band_quantile_bundles) gives, row by row, what np.percentile /
+    np.nanpercentile give on each plane: every quantile, scalar q (float32 virtual index) and tuple q (float64)."""
+    from rsseg.quantiles import lerp_rows, percentile_plan
+    rng = np.random.default_rng(n)
+    m = min(n, 4000)
+    planes = [np.sort((rng.integers(0, 255, m) + (rng.random(m) < 0.5) * rng.random(m)).astype(np.float32)) for _ in range(5)]
+    for q, scalar in [(2, True), (98, True), (50, True), (0, True), (100, True), (37.5, True), ((25.0, 75.0), False), ((10.0, 50.0, 99.9), False)]:
+        ranks, fin = percentile_plan(n, q, np.float32, scalar)
+        # the order statistics a select would fetch: any sorted values will do for ranks beyond the sample
+        vals = np.stack([pl[np.minimum(np.asarray(ranks) * m // max(n, 1), m - 1)] for pl in planes])
+        vals = np.sort(vals.reshape(len(planes), 2, -1), axis=1).reshape(len(planes), -1)   # prev <= next, column by column
+        got = lerp_rows(fin, vals)
+        for i in range(len(planes)):
+            want = fin(vals[i])
+            assert np.asarray(got[i]).dtype == np.asarray(want).dtype
+            assert np.array_equal(got[i], want), (n, q, i)
+        if n == m:   # and against NumPy itself on the full sample
+            exact = np.stack([pl[ranks] for pl in planes])
+            for i, pl in enumerate(planes):
+                assert np.array_equal(lerp_rows(fin, exact)[i], np.percentile(pl, q))
+
+
 @pytest.mark.parametrize("n,k,dt", [(5, 2, np.float32), (9216, 6, np.float32), (360000, 8, np.float32), (1000003, 7, np.float64),
                                     (12345677, 5, np.float32), (4194304, 8, np.float64), (2999999, 3, np.float32)])
 def test_kmeans_draws_equal_randomstate(n, k, dt):
