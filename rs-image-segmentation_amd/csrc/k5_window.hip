@@ -411,19 +411,23 @@ struct resize_planes {
     float *dst[WIN_MAXP];
 };
 
-// A workgroup owns ONE tile column and walks down it (tile rows by, by + ny, ...): the horizontal taps and weights of a
-// thread's pixel column are computed once instead of per pixel (the per-pixel form spent ~70 vector instructions per pixel,
-// a third of them the float64 coordinate arithmetic: VALU busy 0.78 at 0.44 of the HBM rate), and every tile column stays
-// on one XCD (blockIdx % 8 = tx % 8 when 8 | gx), so the source row a tile shares with the tile below is an L2 hit.
+// A workgroup owns a strip of RS_W = 256 destination columns and R consecutive rows of it, one row per iteration: the
+// horizontal taps and weights of a thread's pixel column are computed once instead of per pixel (the per-pixel form spent ~70
+// vector instructions per pixel, a third of them the float64 coordinate arithmetic), the source row an output row shares with
+// the next one is still in the CU's L1 / the XCD's L2, and a strip column stays on one XCD (blockIdx % 8 = tx % 8 when
+// 8 | gx).  256 columns and not 64: source rows are not 128-byte aligned (16378 floats), so a 64-pixel segment touches three
+// cache lines where two hold its data and the line at each end is fetched again by the neighbouring strip's XCD — 6.8 B/px
+// read for 4 (PMC, r03); a 1 KB segment touches nine for eight.
+#define RS_W 256
 template <bool MM>
 __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int sw, int dh, int dw, double scale_x, double scale_y, int src_row0,
-                                                 int dst_row0, int dh_local, int gx, int gy, int ny, int plane, uint32_t *__restrict__ mm)
+                                                 int dst_row0, int dh_local, int gx, int R, int plane, uint32_t *__restrict__ mm)
 {
     const float *__restrict__ src = pl.src[plane];
     float *__restrict__ dst = pl.dst[plane];
     float mn = INFINITY, mx = -INFINITY;
     const int tx = (int)(blockIdx.x % (unsigned)gx), by = (int)(blockIdx.x / (unsigned)gx);
-    const int px = tx * WG_X + (threadIdx.x & 63);
+    const int px = tx * RS_W + (int)threadIdx.x;
     if (px < dw) {
         // horizontal taps (the arithmetic of resize_px, hoisted)
         float fx = (float)(((double)px + 0.5) * scale_x - 0.5);
@@ -433,9 +437,9 @@ __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int s
         if (sx >= sw - 1) { sx = sw - 1; fx = 0.f; }
         const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
         const float a0 = 1.0f - fx, a1 = fx;
-        for (int ty = by; ty < gy; ty += ny) {
-            const int pyl = ty * WG_Y + (threadIdx.x >> 6);
-            if (pyl >= dh_local) break;
+        const int row_end = min((by + 1) * R, dh_local);
+#pragma unroll 4
+        for (int pyl = by * R; pyl < row_end; pyl++) {
             const int py = pyl + dst_row0;
             float fy = (float)(((double)py + 0.5) * scale_y - 0.5);
             int sy = (int)floorf(fy);
@@ -708,16 +712,17 @@ static int resize_rows(rsseg_ctx *ctx, const float *const *d_src, int nplanes, i
     // ONE extrema read-back and synchronisation for all of them
     for (int p = 0; p < nplanes; p++) {
         prof_scope ps(ctx, "resize");
-        const dim3 g = grid2d(dh_local, dw);
-        // about 8192 workgroups: every tile column gets ny of them, each walking every ny-th tile row
-        const int ny = (int)std::max<int64_t>(1, std::min<int64_t>(g.y, 8192 / std::max<unsigned>(g.x, 1u)));
-        const dim3 pg((unsigned)((int64_t)g.x * ny));
+        // about 8192 workgroups: every 256-column strip gets ny of them, each with R consecutive rows
+        const int gx = (dw + RS_W - 1) / RS_W;
+        const int R = (int)std::max<int64_t>(1, ceil_div64(dh_local, std::max(1, 8192 / gx)));
+        const int ny = (int)std::max<int64_t>(1, ceil_div64(dh_local, R));
+        const dim3 pg((unsigned)((int64_t)gx * ny));
         if (ctx->mm_collect)
-            hipLaunchKernelGGL(k5_resize<true>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, (int)g.x,
-                               (int)g.y, ny, p, ctx->d_mm);
+            hipLaunchKernelGGL(k5_resize<true>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, gx, R, p,
+                               ctx->d_mm);
         else
-            hipLaunchKernelGGL(k5_resize<false>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, (int)g.x,
-                               (int)g.y, ny, p, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k5_resize<false>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, gx, R, p,
+                               (uint32_t *)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());
     RSCHK(mm_end(ctx, nplanes));
