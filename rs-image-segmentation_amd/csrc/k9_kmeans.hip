@@ -272,6 +272,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
         }
         if constexpr (MODE != 0) {
             const double ccp = cc[KPP_MAXL];
+            bool moved = MODE != 2;   // MODE 2: did the pending centre come closer to any of the thread's pixels?
 #pragma unroll
             for (int p = 0; p < PXL; p++) {
                 double d = -2.0 * dotp[p];
@@ -279,14 +280,21 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp(planes_t pl, int F, int64_t
                 d = d + yy[p];
                 T dt = (T)d;
                 dt = dt > (T)0 ? dt : (T)0;
-                if constexpr (MODE == 2) dt = cl[p] < dt ? cl[p] : dt;
+                if constexpr (MODE == 2) {
+                    moved = moved || dt < cl[p];
+                    dt = cl[p] < dt ? cl[p] : dt;
+                }
                 cl[p] = dt;
             }
             if (FULL || base + PXL <= n) {
-                typename vt<T>::vec o;
-                if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
-                else o = make_double2(cl[0], cl[1]);
-                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+                // the closest-distance plane is rewritten only where it changed (a new centre takes over ~1 / (r + 1) of the pixels
+                // in round r): less of the write stream that costs a sweep ~10 % of its read rate (profiles/r02_streams.json)
+                if (moved) {
+                    typename vt<T>::vec o;
+                    if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                    else o = make_double2(cl[0], cl[1]);
+                    *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+                }
             } else {
                 for (int p = 0; p < PXL; p++)
                     if (base + p < n) closest[base + p] = cl[p];
@@ -751,6 +759,7 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_blk(planes_t pl, int F, int
         }
         if constexpr (MODE != 0) {
             const double ccp = cc[KPP_MAXL];
+            bool moved = MODE != 2;   // MODE 2: did the pending centre come closer to any of the thread's pixels?
 #pragma unroll
             for (int p = 0; p < PXL; p++) {
                 double d = -2.0 * dotp[p];
@@ -758,14 +767,21 @@ __global__ __launch_bounds__(KM_THREADS) void km_kpp_blk(planes_t pl, int F, int
                 d = d + yy[p];
                 T dt = (T)d;
                 dt = dt > (T)0 ? dt : (T)0;
-                if constexpr (MODE == 2) dt = cl[p] < dt ? cl[p] : dt;
+                if constexpr (MODE == 2) {
+                    moved = moved || dt < cl[p];
+                    dt = cl[p] < dt ? cl[p] : dt;
+                }
                 cl[p] = dt;
             }
             if (FULL || base + PXL <= n) {
-                typename vt<T>::vec o;
-                if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
-                else o = make_double2(cl[0], cl[1]);
-                *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+                // the closest-distance plane is rewritten only where it changed (a new centre takes over ~1 / (r + 1) of the pixels
+                // in round r): less of the write stream that costs a sweep ~10 % of its read rate (profiles/r02_streams.json)
+                if (moved) {
+                    typename vt<T>::vec o;
+                    if constexpr (PXL == 4) o = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                    else o = make_double2(cl[0], cl[1]);
+                    *reinterpret_cast<typename vt<T>::vec *>(closest + base) = o;
+                }
             } else {
                 for (int p = 0; p < PXL; p++)
                     if (base + p < n) closest[base + p] = cl[p];
