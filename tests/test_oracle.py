@@ -169,6 +169,10 @@ SKIMAGE_DOC_COUNTS = [
 ]
 
 
+SKIMAGE_TEST_PROPS = [("homogeneity", 0.80833333, 5e-9), ("energy", 0.38188131, 5e-9), ("correlation", 0.71953255, 5e-9),
+                      ("dissimilarity", 0.418, 2e-3)]
+
+
 def test_glcm_matches_skimage_docstring_vectors(oracle):
     """Pins the angle convention (offsets (0,1), (1,1), (1,0), (1,-1)), the pair loop and the contrast formula of the
     GLCM restatement to the vectors scikit-image publishes; then the windowed mode 0 / mode 1 means over the four
@@ -181,6 +185,11 @@ def test_glcm_matches_skimage_docstring_vectors(oracle):
         assert np.array_equal(sym, counts + counts.T)
         per_angle.append(props)
     assert abs(per_angle[0]["contrast"] - 0.58333333) < 5e-9 and per_angle[2]["contrast"] == 1.0
+    # the known answers scikit-image's own test-suite asserts for this image at distance 1, angle 0, symmetric + normed
+    # (skimage/feature/tests/test_texture.py: test_homogeneity 0.80833333, test_energy 0.38188131, test_correlation
+    # 0.71953255, test_dissimilarity 0.418 to three decimals): the other properties of the restatement, pinned the same way
+    for key, want, tol in SKIMAGE_TEST_PROPS:
+        assert abs(per_angle[0][key] - want) < tol, (key, per_angle[0][key])
     # hand values of the other two angles from the published matrices: sum G (i-j)^2 / sum G = 16/9 and 4/9
     assert abs(per_angle[1]["contrast"] - 16 / 9) < 1e-15 and abs(per_angle[3]["contrast"] - 4 / 9) < 1e-15
     for mode in (0, 1):
