@@ -243,6 +243,47 @@ def test_morphology_and_laplacian_restatements_vs_scipy(oracle):
     assert np.all(feats["opening_5"] <= feats["closing_5"])
 
 
+def test_cv2_skimage_restatements_known_answers(oracle):
+    """OpenCV and scikit-image are not installed and the reference holds no per-stage vectors, so the restatements of
+    cv2.resize / boxFilter / GaussianBlur / Sobel and skimage local_binary_pattern / rank.entropy are pinned to values
+    that follow BY HAND from the published definitions (conventions: half-pixel centres with edge clamping; BORDER_REFLECT_101;
+    the fixed 8-bit kernel [1 4 6 4 1] / 16 of a 5-tap GaussianBlur with sigma 0; LBP 'uniform' = number of ones of a
+    pattern with <= 2 transitions, neighbours sampled bilinearly, >= the centre, zero outside the image; Shannon entropy
+    in bits over the disk footprint)."""
+    # cv2.resize, INTER_LINEAR: fx = (dx + 0.5) * scale - 0.5, clamped at the edges
+    assert np.array_equal(oracle.resize_bilinear(np.array([[0, 1]], np.float32), 1, 4), np.array([[0, 0.25, 0.75, 1]], np.float32))
+    want = np.add.outer(np.array([0, 0.5, 1.5, 2], np.float32), np.array([0, 0.25, 0.75, 1], np.float32))
+    assert np.array_equal(oracle.resize_bilinear(np.array([[0, 1], [2, 3]], np.float32), 4, 4), want)
+    assert np.array_equal(oracle.resize_bilinear(want, 4, 4), want)                      # identity size: the identity
+    # cv2.boxFilter / blur 3 x 3 on a ramp, BORDER_REFLECT_101: column 0 averages (x1, x0, x1)
+    ramp = np.tile(np.arange(12, dtype=np.float32), (12, 1))
+    bm = oracle.box_mean(ramp, 3, "reflect101")
+    assert abs(bm[5, 0] - 2 / 3) < 1e-6 and np.allclose(bm[5, 1:11], np.arange(1, 11)) and abs(bm[5, 11] - (10 + 11 + 10) / 3) < 1e-5
+    # cv2.GaussianBlur(u8, (5, 5), 0): impulse response = round(255 * outer([1 4 6 4 1], [1 4 6 4 1]) / 256)
+    imp = np.zeros((9, 9), np.uint8)
+    imp[4, 4] = 255
+    k = np.array([1, 4, 6, 4, 1])
+    assert np.array_equal(oracle.gaussian_blur_u8(imp, 5)[2:7, 2:7], np.round(255 * np.outer(k, k) / 256).astype(np.uint8))
+    assert oracle.gaussian_blur_u8(np.full((9, 9), 77, np.uint8), 15).min() == 77 == oracle.gaussian_blur_u8(np.full((9, 9), 77, np.uint8), 15).max()
+    # cv2.Sobel 3 x 3 on a unit ramp in x: gx = (1 + 2 + 1) * 2 = 8 everywhere inside, gy = 0; REFLECT_101 makes the border columns 0
+    r8 = np.tile(np.arange(0, 40, dtype=np.float32), (8, 1))
+    p = np.pad(r8, 1, mode="reflect")
+    gx = (p[0:8, 2:] - p[0:8, :-2]) + 2 * (p[1:9, 2:] - p[1:9, :-2]) + (p[2:10, 2:] - p[2:10, :-2])
+    assert np.all(gx[:, 1:-1] == 8) and np.all(gx[:, 0] == 0) and np.all(gx[:, -1] == 0)
+    sm = oracle.sobel_mag_feature(r8)        # the feature: magnitude / max after the stage's own normalisation -> 1 inside, 0 at the border columns
+    assert np.all(sm[:, 0] == 0) and np.all(sm[:, -1] == 0) and sm.max() == pytest.approx(1.0, abs=1e-9)
+    # skimage.feature.local_binary_pattern(P = 24, R = 3, 'uniform'): a flat interior has all 24 neighbours >= the centre
+    lb = oracle.lbp_uniform(np.full((16, 16), 7, np.uint8))
+    assert np.all(lb[3:13, 3:13] == 24)
+    # skimage.filters.rank.entropy(disk(1)): five pixels; four of one value and one of another -> H(0.8, 0.2) bits
+    half = np.zeros((11, 11), np.uint8)
+    half[:, 6:] = 9
+    en = oracle.rank_entropy(half, 1)
+    h = -(0.8 * np.log2(0.8) + 0.2 * np.log2(0.2))
+    assert np.all(en[5, :5] == 0) and np.all(en[5, 7:] == 0) and abs(en[5, 5] - h) < 1e-6 and abs(en[5, 6] - h) < 1e-6
+    assert oracle.disk(1).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]] and int(oracle.disk(3).sum()) == 29 and int(oracle.disk(5).sum()) == 81
+
+
 def test_pin_report_is_committed(golden_dir):
     rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))
     assert rep["class_map_agreement"] >= 0.999
