@@ -610,18 +610,20 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
 #pragma unroll
             for (int f = 0; f < FR; f++) {
                 if (f < F) {
-                    long long q[PXL];
+                    // RAW bit patterns of fma(x, 2^40, 1.5 * 2^52): the constant's pattern is taken off once per chunk and
+                    // cluster (count x constant, modulo 2^64) in the epilogue instead of once per value (as in k3_gram)
+                    unsigned long long q[PXL];
 #pragma unroll
-                    for (int p = 0; p < PXL; p++) q[p] = to_fixed40((double)x[f][p]);
+                    for (int p = 0; p < PXL; p++) q[p] = (unsigned long long)__double_as_longlong(fma((double)x[f][p], 1099511627776.0, FX_MAGIC));
                     if (same) {  // one add for the lane's PXL pixels
-                        long long qs = q[0];
+                        unsigned long long qs = q[0];
 #pragma unroll
                         for (int p = 1; p < PXL; p++) qs += q[p];
-                        atomicAdd(&myS[lab[0] * F + f], (unsigned long long)qs);
+                        atomicAdd(&myS[lab[0] * F + f], qs);
                     } else {
 #pragma unroll
                         for (int p = 0; p < PXL; p++)
-                            if (valid[p]) atomicAdd(&myS[lab[p] * F + f], (unsigned long long)q[p]);
+                            if (valid[p]) atomicAdd(&myS[lab[p] * F + f], q[p]);
                     }
                 }
             }
@@ -645,6 +647,11 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
             if (i < KMAX * F + KMAX) {
                 unsigned long long a = 0;
                 for (int c = 0; c < ncopies; c++) a += S[(size_t)c * stride + i];
+                if (i < KMAX * F) {   // a sum: take count x bits(1.5 * 2^52) off the raw patterns
+                    unsigned long long cnt = 0;
+                    for (int c = 0; c < ncopies; c++) cnt += S[(size_t)c * stride + KMAX * F + i / F];
+                    a -= cnt * (unsigned long long)__double_as_longlong(FX_MAGIC);
+                }
                 v = (long long)a;
             } else {
                 v = changed_w[0] + changed_w[1] + changed_w[2] + changed_w[3];
