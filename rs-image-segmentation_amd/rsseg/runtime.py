@@ -8,6 +8,7 @@ xGMI) behind the library's all-reduce hook.  All arithmetic on rasters happens i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
