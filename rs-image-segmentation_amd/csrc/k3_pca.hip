@@ -80,7 +80,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_gram(pca_args a, int64_t n, lo
     pca_fill_lut<NB, TAB>(a, lut);
     bool miss = false;
     auto tab = [&](int b, float v) {   // FL: the table entry of an integer-valued v in [0, 255]
-        const int idx = (int)v;
+        const int idx = (int)fminf(fmaxf(v, -1.f), 256.f);   // NaN and anything outside [0, 255] convert to a defined, missing index
         miss = miss || !(v == (float)idx && (unsigned)idx < 256u);
         return lut[b * 256 + (idx & 255)];
     };
