@@ -496,6 +496,27 @@ def test_kmeans_full_scene_vs_reference_goldens(ctx, scene, oracle, golden_dir):
         assert np.array_equal(order, pair), k
 
 
+def test_config2_at_its_real_size_equals_the_oracle(ctx, oracle):
+    """BASELINE configs[1] at its real size, exact: the 4096 x 4096 synthetic TM raster (SURVEY 8d generator), percentile
+    normalisation + 7 spectral indices + KMeans(k = 6) — label map, seeds, iteration count and centres against the CPU
+    oracle (about a minute of CPU time; the one full-size case the oracle reaches)."""
+    from rsseg import pipeline as P
+    H = W = 4096
+    r = oracle.synthetic_raster(H, W, bands=5)
+    labels, meta, planes = P.config2(ctx, [dev(ctx, r[i].reshape(-1)) for i in range(5)], 6)
+    got = host(labels)
+    b, g, rd, n, s = [oracle.robust_normalize(r[i]) for i in range(5)]
+    ref_planes = [oracle.calculate_ndvi(n, rd), oracle.calculate_evi(n, rd, b), oracle.calculate_msavi(n, rd), oracle.calculate_ndwi(g, n),
+                  oracle.calculate_mndwi(g, s), oracle.calculate_ndbi(s, n), oracle.calculate_bsi(b, rd, n, s)]
+    for name, gp, rp in zip(P.INDEX_NAMES, planes, ref_planes):
+        assert np.array_equal(host(gp).view(np.int32), rp.reshape(-1).view(np.int32)), name
+    want, info = oracle.kmeans_fit_planes([p.reshape(-1) for p in ref_planes], 6)
+    assert meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(meta["init_indices"], info["init_indices"])
+    assert np.array_equal(got, want)
+    assert np.allclose(meta["centers"] - meta["mean"], info["centers"], rtol=0, atol=1e-6)
+
+
 def test_kmeans_errors(ctx):
     x = dev(ctx, np.zeros(3, np.float32))
     with pytest.raises(ValueError):
