@@ -736,10 +736,11 @@ def test_quantile_bundle_equals_separate_selects(ctx, scene, oracle):
     assert np.isnan(q["lo"]) and q["center"] is None
 
 
-def test_config3_pipeline_vs_oracle(ctx, oracle):
-    """BASELINE config 3 on a 192 x 160 synthetic tile: features and labels against the CPU oracle."""
+@pytest.mark.parametrize("H,W", [(192, 160), (2048, 2048)])
+def test_config3_pipeline_vs_oracle(ctx, oracle, H, W):
+    """BASELINE config 3 on a 192 x 160 synthetic tile and on a 2048 x 2048 one (4 Mpixel: 256 k-means chunks, multi-block
+    reductions everywhere — the size bench.py's CPU baseline runs): features and labels against the CPU oracle."""
     from rsseg import pipeline as P
-    H, W = 192, 160
     r = oracle.synthetic_raster(H, W)
     labels, meta, planes = P.config3(ctx, [dev(ctx, r[i]) for i in range(7)], H, W, 8, 7, 1, 3)
     norm = [oracle.robust_normalize(r[i]) for i in range(7)]
@@ -756,7 +757,7 @@ def test_config3_pipeline_vs_oracle(ctx, oracle):
     for i in range(3):
         got = host(planes[12 + i], (H, W))
         assert np.abs(got - truth[i].reshape(H, W)).max() <= 1e-5
-        assert np.abs(got - pcs[i]).max() <= 1e-4
+        assert np.abs(got - pcs[i]).max() <= (1e-4 if H * W < 100000 else 1e-3)   # scikit-learn's float32 Gram: its noise grows with N
     # labels: bit-exact against the oracle KMeans run on the GPU's own feature planes
     want, info = oracle.kmeans_fit_planes([host(p, (H, W)) for p in planes], 8)
     assert meta["n_iter"] == info["n_iter"]
