@@ -99,6 +99,8 @@ class Context:
         import torch.distributed as dist
         if use_dist is None:
             use_dist = dist.is_available() and dist.is_initialized()
+        if force_comm and not use_dist:
+            raise RssegError("force_comm needs an initialised torch.distributed process group")
         if use_dist and (dist.get_world_size(group) > 1 or force_comm):
             self._install_comm(group)
 
