@@ -447,6 +447,31 @@ def test_kmeans_nan_and_ragged_and_constant_feature(ctx, crop, oracle):
     assert meta["n_iter"] == info["n_iter"]
 
 
+def test_pipelines_with_nodata_pixels_in_a_band(ctx, oracle):
+    """scripts/2 turns nodata into NaN (scripts/2_feature_extraction.py:160-175); np.percentile of such a band is NaN, so
+    robust_normalize makes the WHOLE band NaN (indices.py:38-45), every index that reads it is NaN, KMeans clusters NaN as 0
+    (extract.py:560-566) and PCA refuses the stack like scikit-learn.  Config 2 with NaNs in the green band: planes (NaN
+    pattern included) and labels against the oracle; config 3 and the 19-feature stack raise instead of computing."""
+    from rsseg import pipeline as P
+    H, W = 128, 160
+    r = oracle.synthetic_raster(H, W).copy()
+    r[1, 10:14, 20:40] = np.nan
+    bands = [dev(ctx, r[i].reshape(-1)) for i in range(7)]
+    labels, meta, planes = P.config2(ctx, bands, 6)
+    b, g, rd, n, s = [oracle.robust_normalize(r[i]) for i in range(5)]
+    assert np.isnan(g).all()
+    ref_planes = [oracle.calculate_ndvi(n, rd), oracle.calculate_evi(n, rd, b), oracle.calculate_msavi(n, rd), oracle.calculate_ndwi(g, n),
+                  oracle.calculate_mndwi(g, s), oracle.calculate_ndbi(s, n), oracle.calculate_bsi(b, rd, n, s)]
+    for name, gp, rp in zip(P.INDEX_NAMES, planes, ref_planes):
+        assert np.array_equal(host(gp, (H, W)), rp, equal_nan=True), name
+    want, info = oracle.kmeans_fit_planes([p.reshape(-1) for p in ref_planes], 6)
+    assert meta["n_iter"] == info["n_iter"] and np.array_equal(host(labels), want)
+    with pytest.raises(Exception, match="NaN"):
+        P.config3(ctx, bands, H, W, 8, 7, 1, 3)
+    with pytest.raises(Exception, match="NaN"):
+        P.feature_stack19(ctx, bands, H, W)
+
+
 def test_kmeans_full_scene_bitexact_vs_oracle(ctx, scene, oracle):
     bands = oracle.stage1_preprocess(scene["dn"])
     norm = [oracle.robust_normalize(b) for b in bands]
