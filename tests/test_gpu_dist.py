@@ -261,7 +261,7 @@ class _ThreadWorld:
             raise AssertionError(f"rank {errs[0][0]} failed: {errs[0][1]!r}")
 
 
-@pytest.mark.parametrize("H,W,world", [(203, 136, 8), (203, 136, 5), (9, 40, 8)])
+@pytest.mark.parametrize("H,W,world", [(203, 136, 8), (203, 136, 5), (9, 40, 8), (331, 136, 16)])
 def test_many_stripes_in_threads_equal_single_gpu(ctx, oracle, H, W, world):
     """The 8-way row split of the multi-GPU bench, an uneven 5-way one, and one-row stripes (9 rows over 8 ranks: halos
     wider than the stripes), every rank a thread with its own context:
