@@ -103,6 +103,26 @@ def test_striped_config3_equals_single_gpu(ctx, oracle, tmp_path, world):
     assert np.array_equal(np.concatenate(got), want)
 
 
+def test_comm_arguments_are_checked(ctx):
+    """rsseg_ctx_set_comm: more ranks than RSSEG_MAX_RANKS (16), a rank outside the world, and a failing hook are errors
+    (the last one surfaces as RSSEG_ERR_COMM from the call that needed the collective), never a silent single-rank run."""
+    from rsseg.runtime import Context, RssegError
+    c = Context(0, use_dist=False)
+    try:
+        with pytest.raises(ValueError, match="rank/world"):
+            c.install_comm_hook(0, 17, lambda *a: None)
+        with pytest.raises(ValueError, match="rank/world"):
+            c.install_comm_hook(3, 2, lambda *a: None)
+
+        def broken(buf, offset, count, dtype, op):
+            raise RuntimeError("link down")
+        c.install_comm_hook(0, 2, broken)
+        with pytest.raises(RssegError):
+            c.order_stats(c.to_device(np.arange(1000, dtype=np.float32)), [10])
+    finally:
+        c.close()
+
+
 def test_every_collective_through_a_one_rank_rccl_group(ctx, oracle, tmp_path):
     """The RCCL branch of make_allreduce_hook on the hardware a one-GPU box has: a one-rank `nccl` group, the hook
     installed all the same (Context(force_comm=True)), so that each collective of config 3 and of the 19-feature stack
