@@ -127,7 +127,7 @@ PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 
               "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true", "gram": "k3_gram<7", "project": "k3_project<7, true", "indices_project": "k3_indices_project<7, true",
               "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
 # static VALU instructions of the texture kernels and their measured issue cost (profiles/valu_mix.py ->
-# profiles/r02_valu_issue.json): the bound of the texture kernel is VALU issue, not HBM.  Dense case (window 7, step 1):
+# profiles/r*_valu_issue.json, the newest): the bound of the texture kernel is VALU issue, not HBM.  Dense case (window 7, step 1):
 # k4_glcm_pair, 128 windows per wave; other steps: k4_glcm_thread<7,3>, 64 windows per wave.
 GLCM_VALU = {"insts_per_wave": 2954, "issue_cycles_per_wave": None}
 
@@ -164,8 +164,9 @@ def glcm_issue_cycles(glcm_step=1):
     """(weighted VALU issue cycles per wave, windows per wave, static VALU instructions per wave, kernel) of the texture
     kernel that runs at this step, from the committed microbenchmark summary; cycles None when it is absent."""
     key, kern = ("glcm_pair", "k4_glcm_pair") if glcm_step == 1 else ("glcm_thread_7_3", "k4_glcm_thread<7,3>")
-    f = os.path.join(ROOT, "profiles", "r02_valu_issue.json")
+    import glob
     try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]   # the newest round's histogram of the code object
         e = json.load(open(f))[key]
         return e["issue_cycles_per_wave"], 64 * e["windows_per_thread"], e["valu_static"], kern
     except Exception:  # noqa: BLE001

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """VALU issue bound of k4_glcm_thread<7,3> and k4_glcm_pair from (a) the static instruction histogram of the kernel
-(profiles/r02_glcm_thread_7_3_valu_hist.txt: disassembly of the gfx950 code object, `grep v_ | uniq -c`) and
+(profiles/<round>_glcm_*_valu_hist.txt: disassembly of the gfx950 code object, `grep v_ | uniq -c`) and
 (b) the measured issue cost of each instruction class at 4 waves per SIMD (profiles/r02_ubench.json, produced by
-profiles/ubench/ubench.hip on an MI355X).  Writes profiles/r02_valu_issue.json, which bench.py reads for the
+profiles/ubench/ubench.hip on an MI355X).  Writes profiles/<round>_valu_issue.json (bench.py reads the newest) for the
 roofline entry of the texture kernel:  frac = waves * issue_cycles_per_wave / (1024 SIMDs * 2.4 GHz * measured time).
 
 Measured classes (cycles per wave64 instruction on one SIMD, 4 waves per SIMD, independent streams):
@@ -14,7 +14,10 @@ import json
 import os
 import re
 
+import sys
+
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"   # histogram files <ROUND>_glcm_*_valu_hist.txt -> <ROUND>_valu_issue.json
 ub = json.load(open(os.path.join(HERE, "r02_ubench.json")))["valu"]
 fast = min(v["4_waves_per_simd"] for k, v in ub.items() if k in ("v_add_u32", "v_and_b32", "v_xor_b32"))
 slow = max(v["4_waves_per_simd"] for k, v in ub.items() if k in ("v_pk_min_u16", "v_perm_b32", "v_fma_f64", "v_lshlrev_b32"))
@@ -39,8 +42,8 @@ def price(hist_file, windows_per_thread):
 out = {"source": "profiles/ubench/ubench.hip on MI355X + static histogram of the gfx950 code object",
        "cost_fast_cycles": fast, "cost_slow_cycles": slow,
        # one window per thread: every geometry but the dense one (and the dense one until r02's last day)
-       "glcm_thread_7_3": price("r02_glcm_thread_7_3_valu_hist.txt", 1),
+       "glcm_thread_7_3": price(f"{ROUND}_glcm_thread_7_3_valu_hist.txt", 1),
        # window 7, step 1, levels <= 32: two adjacent windows per thread share the sort of their common keys
-       "glcm_pair": price("r02_glcm_pair_valu_hist.txt", 2)}
-json.dump(out, open(os.path.join(HERE, "r02_valu_issue.json"), "w"), indent=1)
+       "glcm_pair": price(f"{ROUND}_glcm_pair_valu_hist.txt", 2)}
+json.dump(out, open(os.path.join(HERE, f"{ROUND}_valu_issue.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

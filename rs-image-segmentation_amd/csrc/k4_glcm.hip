@@ -159,6 +159,15 @@ __device__ __forceinline__ unsigned pk_sub_sat(unsigned a, unsigned b)
 #endif
     return r;
 }
+// a * b on both 16-bit halves (v_pk_mul_lo_u16)
+__device__ __forceinline__ unsigned pk_mul(unsigned a, unsigned b)
+{
+    unsigned r = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+#endif
+    return r;
+}
 __device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)));
@@ -356,9 +365,8 @@ __device__ __forceinline__ void glcm_group_stats(const unsigned (&w)[8][2], cons
     static_for<P - 1>([&](auto I) {
         constexpr int i = I + 1;
         const unsigned diag = K[i] & one;
-        const unsigned ne = pk_min_opaque(K[i] ^ K[i - 1], one);  // 0 where equal, 1 where different
-        const unsigned keep = pk_sub(ne, one);                    // 0xffff where equal, 0 where different
-        t = (t + one + diag) & keep;
+        const unsigned eq = pk_sub_sat(one, K[i] ^ K[i - 1]);     // 1 where equal, 0 where different
+        t = pk_mul(t + one + diag, eq);
         E2 += t;
         D += diag;
     });
@@ -605,9 +613,8 @@ template <int NK, typename NET> __device__ __forceinline__ void gp_runlength(con
     static_for<NK - 1>([&](auto I) {
         constexpr int i = NET::net.order[I + 1], j = NET::net.order[I];
         const unsigned diag = K[i] & one;
-        const unsigned ne = pk_min_opaque(K[i] ^ K[j], one);
-        const unsigned keep = pk_sub(ne, one);
-        t = (t + one + diag) & keep;
+        const unsigned eq = pk_sub_sat(one, K[i] ^ K[j]);   // 1 where the keys are equal, 0 where they differ
+        t = pk_mul(t + one + diag, eq);
         E2 += t;
         D += diag;
     });
