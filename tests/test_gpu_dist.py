@@ -119,6 +119,23 @@ def test_comm_arguments_are_checked(ctx):
         c.install_comm_hook(0, 2, broken)
         with pytest.raises(RssegError):
             c.order_stats(c.to_device(np.arange(1000, dtype=np.float32)), [10])
+        # a hook that fails in the MIDDLE of KMeans (stream-ordered collectives between enqueued kernels): the call reports
+        # it, and the context keeps working afterwards
+        calls = {"n": 0}
+
+        def flaky(buf, offset, count, dtype, op):
+            calls["n"] += 1
+            if calls["n"] == 9:
+                raise RuntimeError("link down")
+        c.install_comm_hook(0, 1, flaky)     # one rank: identity reductions, the hook is called all the same
+        rng = np.random.default_rng(3)
+        planes = [c.to_device(rng.random(50000).astype(np.float32)) for _ in range(4)]
+        with pytest.raises(RssegError):
+            c.kmeans_fit_predict(planes, 5)
+        assert calls["n"] == 9
+        labels, meta = c.kmeans_fit_predict(planes, 5)          # the hook works again: a complete fit
+        ref, meta0 = ctx.kmeans_fit_predict([ctx.to_device(p.cpu().numpy()) for p in planes], 5)
+        assert meta["n_iter"] == meta0["n_iter"] and np.array_equal(labels.cpu().numpy(), ref.cpu().numpy())
     finally:
         c.close()
 
