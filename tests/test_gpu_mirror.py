@@ -57,6 +57,28 @@ def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
     assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(nir)) and fr["laplacian"].dtype == np.float32
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (2, 2), (1, 9), (3, 3), (9, 1), (4, 17)])
+def test_window_operators_on_rasters_smaller_than_their_windows(ctx, oracle, shape):
+    """Rasters smaller than the 3 / 5 / 7-pixel windows (the border rule then reflects more than once — cv2's
+    borderInterpolate loops until the index is inside, like NumPy's 'reflect'): every member against the oracle."""
+    from modules.features import indices as I
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    band = rng.random(shape).astype(np.float32)
+    mf = I.calculate_morphological_features(band)
+    want = oracle.calculate_morphological_features(band)
+    for k in want:
+        assert np.array_equal(mf[k], want[k]), (shape, k)
+    ms = I.calculate_multi_scale_features(band)
+    for sc in (3, 5, 7):
+        assert np.array_equal(ms[f"std_dev_scale_{sc}"], oracle.std_dev_feature(band, sc)), (shape, sc)
+        assert np.array_equal(ms[f"variance_scale_{sc}"], oracle.variance_feature(band, sc)), (shape, sc)
+    fr = I.calculate_filter_responses(band)
+    assert np.array_equal(fr["sobel_mag"], oracle.sobel_mag_feature(band), equal_nan=True), shape
+    assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(band), equal_nan=True), shape
+    ctxm = I.add_spatial_context(np.stack([band.astype(np.float64)] * 2, axis=-1), 7)
+    assert np.array_equal(ctxm, oracle.add_spatial_context(np.stack([band.astype(np.float64)] * 2, axis=-1), 7)), shape
+
+
 def test_stage_takes_uint8_bands_like_float32_bands(ctx, crop):
     """8-bit rasters cross PCIe as one byte per pixel and are widened on the device (Context.upload_f32): the stage's
     outputs equal those of the same bands handed over as float32, bit for bit."""
