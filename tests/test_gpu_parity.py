@@ -542,6 +542,19 @@ def test_config2_at_its_real_size_equals_the_oracle(ctx, oracle):
     assert np.allclose(meta["centers"] - meta["mean"], info["centers"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,F,k", [(50, 3, 1), (6, 2, 6), (7, 1, 3), (1000, 1, 2), (5000, 64, 2), (2, 1, 2), (300, 5, 64)])
+def test_kmeans_corner_sizes(ctx, oracle, n, F, k):
+    """One cluster, as many clusters as points, one feature, the widest plane count, k = RSSEG's 64: labels, seeds and
+    iteration count against the oracle (which equals scikit-learn on such inputs, tests/test_oracle.py)."""
+    rng = np.random.default_rng(n * 1000 + F * 10 + k)
+    planes = [rng.random(n).astype(np.float32) for _ in range(F)]
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    labels, meta = ctx.kmeans_fit_predict([dev(ctx, p) for p in planes], k)
+    assert meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(meta["init_indices"], info["init_indices"])
+    assert np.array_equal(host(labels), want)
+
+
 def test_kmeans_errors(ctx):
     x = dev(ctx, np.zeros(3, np.float32))
     with pytest.raises(ValueError):
