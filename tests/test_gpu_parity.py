@@ -693,6 +693,26 @@ def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
     assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
+def test_forest_degenerate_shapes_vs_sklearn(ctx, oracle):
+    """A forest whose trees are single leaves (one class in the training set), a single tree, a single stump, one pixel
+    and an empty raster: the walk has nothing to walk, the vote table has one row per leaf."""
+    from sklearn.ensemble import RandomForestClassifier
+    rng = np.random.default_rng(77)
+    Xtr = rng.random((200, 5)).astype(np.float32)
+    X = rng.random((1031, 5)).astype(np.float32)
+    cases = {
+        "one_class": RandomForestClassifier(n_estimators=7, random_state=0).fit(Xtr, np.full(200, 3)),
+        "one_tree": RandomForestClassifier(n_estimators=1, max_depth=6, random_state=0).fit(Xtr, (Xtr[:, 1] * 4).astype(int)),
+        "stumps": RandomForestClassifier(n_estimators=5, max_depth=1, random_state=0).fit(Xtr, (Xtr[:, 0] > 0.5).astype(int) * 7 + 2),
+    }
+    for name, model in cases.items():
+        ctx.forest_load(oracle.flatten_forest(model))
+        got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(5)]))
+        assert np.array_equal(got, model.predict(X)), name
+        one = host(ctx.forest_predict([dev(ctx, X[:1, i]) for i in range(5)]))
+        assert np.array_equal(one, model.predict(X[:1])), name
+
+
 @pytest.mark.parametrize("F", [1, 2, 8, 32, 33, 55, 64])
 def test_forest_feature_counts_vs_sklearn(ctx, oracle, F):
     """Feature counts 1, even, 32 (the last count with 1024 pixels per workgroup) and 33 / 55 / 64 (512 pixels per
