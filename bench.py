@@ -273,6 +273,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--rccl-single", action="store_true", help="N = 1: a one-rank RCCL group with the all-reduce hook installed, so that every collective of a step (identity reductions) goes through torch.distributed / RCCL on this GPU")
+    ap.add_argument("--comm", choices=["native", "torch"], default=None,
+                    help="how the all-reduces are issued: 'native' = the library's own RCCL communicator (ncclAllReduce from C on the context's "
+                         "stream; default with backend nccl), 'torch' = the callback into torch.distributed.all_reduce (default with gloo)")
     ap.add_argument("--launch-selftest", action="store_true", help="no GPU: every rank joins a gloo rendezvous on the CPU and rank 0 prints one line")
     args = ap.parse_args()
 
@@ -316,7 +319,7 @@ def main():
             dist.init_process_group(args.backend)
     from rsseg import pipeline as P
     from rsseg.runtime import Context
-    ctx = Context(local, force_comm=args.rccl_single and world == 1)
+    ctx = Context(local, force_comm=args.rccl_single and world == 1, comm=args.comm)
 
     cfg = args.config
     H = W = args.size or (4096 if cfg == "c2" else 16384)
@@ -537,6 +540,9 @@ def main():
                                        if world > 1 else ("single GPU, every collective through a one-rank RCCL group" if args.rccl_single else "single GPU")),
                        "host_syncs_per_step": round(host_syncs / args.steps, 1),
                        "allreduce_per_step": comm_cnt / args.steps, "allreduce_host_ms_per_step": round(comm_ms / args.steps, 3),
+                       "comm": ctx.comm_kind and {"native": "RCCL from C (rsseg_ctx_set_comm_rccl: ncclAllReduce on the context's stream)",
+                                                  "torch": "callback into torch.distributed.all_reduce"}[ctx.comm_kind],
+                       "allreduce_host_us_per_collective": round(1e3 * comm_ms / comm_cnt, 1) if comm_cnt else None,
                        **extras},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -87,6 +87,25 @@ int rsseg_ctx_sync(rsseg_ctx *ctx);
 int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_allreduce_fn fn, void *user,
                        void *d_comm, size_t comm_bytes);
 
+/* The same with RCCL driven by the library itself (no callback, no Python in the loop): every reduction becomes an
+ * ncclAllReduce, in place in the communication buffer, enqueued on the context's stream.  Rank 0 obtains the 128-byte
+ * ncclUniqueId with rsseg_rccl_unique_id and the host hands it to every rank by whatever means it has (torch.distributed's
+ * store, MPI, a file); then EVERY rank calls rsseg_ctx_set_comm_rccl (collective: ncclCommInitRank).  librccl_path names
+ * the librccl.so the process uses (torch ships one in torch/lib; NULL: "librccl.so.1" from the loader path); it is
+ * dlopen()ed, not linked.  d_comm may be NULL: the library then owns a 4 MiB buffer.  world == 1 is allowed (identity
+ * reductions through RCCL).  rsseg_ctx_set_comm or rsseg_ctx_destroy release the communicator.
+ * (This is the form SURVEY.md 8b sketched as rsseg_ctx_create(device, rank, world, ncclUniqueId*).) */
+#define RSSEG_RCCL_ID_BYTES 128
+int rsseg_rccl_unique_id(const char *librccl_path, void *id_out);
+int rsseg_ctx_set_comm_rccl(rsseg_ctx *ctx, int rank, int world, const void *unique_id, const char *librccl_path, void *d_comm,
+                            size_t comm_bytes);
+
+/* One reduction over whatever communication path is installed (callback or RCCL), as the library's own kernels use it:
+ * `count` elements of `dtype` at byte `offset` of the communication buffer, in place, enqueued on the context's stream
+ * (no host wait).  Without a communication path (one rank) it is the identity.  For hosts that keep cross-rank values of
+ * their own in the buffer, and for testing a path's stream ordering. */
+int rsseg_ctx_allreduce(rsseg_ctx *ctx, int64_t offset, int64_t count, int dtype, int op);
+
 /* Per-kernel timing (HIP events on the context's stream, around each launch of the named
  * kernel family).  Used by bench.py for the roofline object.  name: "glcm", "lloyd", "indices", "normalize", "quantize", "range",
  * "select", "kpp", "moment" (KMeans' column means), "labels" (uint8 -> int32 label plane), "box" (one plane), "ctxmean" (several planes per launch), "morph", "filt_max" / "filt_write" (the two passes
@@ -319,18 +338,31 @@ int rsseg_threshold_band_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float 
  * nan_as_zero = 0 leaves a NaN pixel outside every interval (both comparisons are false); nan_as_zero = 1 is
  * rsseg_threshold_band_f32. */
 int rsseg_band_interval_f32(rsseg_ctx *ctx, const float *d_x, int64_t n, float lo, float hi, int nan_as_zero, uint8_t *d_out);
+/* The same on a float64 plane (the comparisons of a float64 feature with a Python-float threshold are float64 comparisons). */
+int rsseg_band_interval_f64(rsseg_ctx *ctx, const double *d_x, int64_t n, double lo, double hi, int nan_as_zero, uint8_t *d_out);
+/* threshold_segmentation(..., otsu=True) (extract.py:358-371): NaN -> 0; *vmin / *vmax = the plane's extrema; when they are
+ * equal d_out is all 0 (above) / all 1 and *level = -1; otherwise the plane is stretched to uint8 in its own dtype
+ * (np.clip((x - min) / (max - min + 1e-10) * 255, 0, 255).astype(uint8)), *level = cv2.threshold(THRESH_OTSU)'s level of its
+ * 256-bin histogram (OpenCV's getThreshVal_Otsu_8u restated), and d_out = q > level (above) or its complement.
+ * dtype: RSSEG_F32 or RSSEG_F64.  Whole raster on one GPU. */
+int rsseg_otsu_mask(rsseg_ctx *ctx, const void *d_x, int dtype, int64_t n, int above, uint8_t *d_out, int *level, double *vmin,
+                    double *vmax);
 /* Mask algebra of extract_builtup_by_threshold / extract_bareland_by_rule (extract.py:447-505) on 0 / 1 planes:
  * op 0: a & b, 1: a | b, 2: a & !b, 3: !a (d_b may be NULL).  d_out may alias an input. */
 int rsseg_mask_op_u8(rsseg_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int64_t n, int op, uint8_t *d_out);
 /* final_map[mask == 1] = value, or only where final_map == 0 (scripts/3_classification.py:361-363, 373). */
 int rsseg_mask_paint_u8(rsseg_ctx *ctx, uint8_t *d_map, const uint8_t *d_mask, int64_t n, int value, int only_unset);
-/* cv2.morphologyEx / erode / dilate with cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)), k in {3, 5}, on a uint8
+/* cv2.morphologyEx / erode / dilate with cv2.getStructuringElement(MORPH_ELLIPSE, (k, k)), k odd in 3 ... 31, on a uint8
  * plane (advanced_post_processing, extract.py:311-313, 334-336): op = RSSEG_MORPH_ERODE / DILATE / OPEN / CLOSE. */
 int rsseg_morph_ellipse_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, int k, int op, uint8_t *d_out);
 /* scipy.ndimage.label(mask, structure=ones((3,3))) + the np.bincount area filter (extract.py:319-329): d_out = mask
  * without its 8-connected components of fewer than min_area pixels.  Whole raster on one GPU (components cross
  * stripes, so this operator is not row-sharded). */
 int rsseg_remove_small_components_u8(rsseg_ctx *ctx, const uint8_t *d_mask, int H, int W, int min_area, uint8_t *d_out);
+/* scipy.ndimage.binary_fill_holes(mask) (advanced_post_processing's branch for an even or zero smooth_kernel_size,
+ * extract.py:314-316): d_out = mask plus every 4-connected background component that touches no image border.
+ * Whole raster on one GPU. */
+int rsseg_fill_holes_u8(rsseg_ctx *ctx, const uint8_t *d_mask, int H, int W, uint8_t *d_out);
 
 /* ---- K13: remaining texture members of the feature dictionary ---------------- */
 /* calculate_lbp_features (indices.py:320-344): skimage.feature.local_binary_pattern(u8, n_points, radius, 'uniform');

@@ -624,11 +624,17 @@ def filter_responses_extra(band: np.ndarray) -> dict:
 # restated (cv2 absent): (3,3) = cross, (5,5) = 5x5 without the corner pairs; out-of-image taps never win.
 # --------------------------------------------------------------------------------------------
 def ellipse_element(k: int) -> np.ndarray:
-    if k == 3:
-        return np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
-    if k == 5:
-        return np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)
-    raise ValueError(k)
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)) restated from OpenCV's imgproc/morph.cpp: r = c = k // 2,
+    row i (dy = i - r) is 1 for |j - c| <= cvRound(c * sqrt((r*r - dy*dy) / (r*r))); cvRound rounds half to even.
+    (3,3) is the cross; (5,5) the square without its corner pairs."""
+    r = c = k // 2
+    se = np.zeros((k, k), np.uint8)
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    for i in range(k):
+        dy = i - r
+        dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+        se[i, max(c - dx, 0):min(c + dx + 1, k)] = 1
+    return se
 
 
 def morph_ellipse(mask: np.ndarray, k: int, op: str) -> np.ndarray:
@@ -659,10 +665,17 @@ def morph_ellipse(mask: np.ndarray, k: int, op: str) -> np.ndarray:
             "closing": lambda: erode(dilate(x))}[op]()
 
 
-def advanced_post_processing(binary_mask: np.ndarray, min_area=100, smooth_kernel_size=3) -> np.ndarray:
-    """extract.py:299-341 (odd kernel sizes)."""
+def advanced_post_processing(binary_mask: np.ndarray, min_area=100, smooth_kernel_size=3, fill_holes=True) -> np.ndarray:
+    """extract.py:299-341.  The hole fill of the even / zero kernel branch CALLS scipy.ndimage.binary_fill_holes and the
+    component filter scipy.ndimage.label — the reference's own dependency, installed."""
     from scipy import ndimage
-    m = morph_ellipse(binary_mask.astype(np.uint8), smooth_kernel_size, "closing")
+    k = smooth_kernel_size
+    odd = k > 0 and k % 2 == 1
+    m = binary_mask.astype(np.uint8)
+    if fill_holes and odd:
+        m = morph_ellipse(m, k, "closing")
+    elif fill_holes:
+        m = ndimage.binary_fill_holes(m).astype(np.uint8)
     if min_area > 0:
         lab, nf = ndimage.label(m, structure=np.ones((3, 3)))
         if nf > 0:
@@ -670,7 +683,50 @@ def advanced_post_processing(binary_mask: np.ndarray, min_area=100, smooth_kerne
             rm = np.where((area < min_area) & (area > 0))[0]
             if rm.size > 0:
                 m[np.isin(lab, rm)] = 0
-    return morph_ellipse(m, smooth_kernel_size, "opening")
+    return morph_ellipse(m, k, "opening") if odd else m
+
+
+def otsu_level_u8(u8: np.ndarray) -> int:
+    """cv2.threshold(u8, 0, 255, THRESH_BINARY + THRESH_OTSU)'s level, restated from OpenCV's imgproc/thresh.cpp
+    (getThreshVal_Otsu_8u; cv2 is absent: RESTATEMENT ONLY, pinned by hand-derived cases in tests/test_oracle.py): scan
+    the 256 levels upwards, keep the first level with the largest between-class variance q1*q2*(mu1-mu2)^2, skipping
+    levels whose class weights are within FLT_EPSILON of 0 or 1; float64."""
+    h = np.bincount(u8.ravel(), minlength=256).astype(np.float64)
+    scale = 1.0 / u8.size
+    mu = 0.0
+    for i in range(256):            # the same left-to-right float64 sum as the C loop
+        mu += i * h[i]
+    mu *= scale
+    eps = float(np.finfo(np.float32).eps)
+    mu1 = q1 = max_sigma = 0.0
+    best = 0
+    for i in range(256):
+        p_i = h[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2)
+        if sigma > max_sigma:
+            max_sigma, best = sigma, i
+    return best
+
+
+def threshold_segmentation(feature_image: np.ndarray, threshold_value, above=True, otsu=False) -> np.ndarray:
+    """extract.py:344-404 (without the cv2.error fallback, which valid input never takes)."""
+    if np.isnan(feature_image).any():
+        feature_image = np.nan_to_num(feature_image, nan=0.0)
+    if otsu:
+        mn, mx = np.min(feature_image), np.max(feature_image)
+        if mx == mn:
+            return np.zeros_like(feature_image, dtype=np.uint8) if above else np.ones_like(feature_image, dtype=np.uint8)
+        norm = np.clip(((feature_image - mn) / (mx - mn + 1e-10) * 255), 0, 255).astype(np.uint8)
+        mask = (norm > otsu_level_u8(norm)).astype(np.uint8)
+        return mask if above else (1 - mask).astype(np.uint8)
+    return (feature_image > threshold_value).astype(np.uint8) if above else (feature_image < threshold_value).astype(np.uint8)
 
 
 def rule_based_classification(features: dict) -> np.ndarray:

@@ -45,6 +45,8 @@ struct rsseg_ctx {
     char *d_comm = nullptr;
     size_t comm_bytes = 0;
     char *h_comm = nullptr;   // pinned staging of the communication buffer (comm_bytes)
+    void *rccl_comm = nullptr;   // ncclComm_t when the library drives RCCL itself (rsseg_ctx_set_comm_rccl)
+    bool own_comm_buf = false;   // d_comm was allocated by the library
     // workspace (device) and pinned host staging
     char *d_ws = nullptr;
     size_t ws_bytes = 0;

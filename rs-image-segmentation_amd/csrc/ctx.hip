@@ -1,7 +1,9 @@
 // Context, workspace, communication hook and per-kernel timers of librsseg_hip.so.
+#include <dlfcn.h>
 #include <stdarg.h>
 
 #include <chrono>
+#include <mutex>
 
 #include "common.h"
 
@@ -57,6 +59,149 @@ extern "C" int rsseg_ctx_create(int device, void *stream, rsseg_ctx **out)
     return RSSEG_OK;
 }
 
+// ---- RCCL driven by the library itself -------------------------------------------------------------------------------
+// librccl is not a link-time dependency: the host names the copy its process already uses (torch ships one in torch/lib)
+// and the five entry points are bound with dlsym.  The declarations below restate rccl.h (ncclUniqueId: 128 opaque bytes
+// passed BY VALUE; ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8; ncclSum = 0, ncclMax = 2, ncclMin = 3).
+struct rs_nccl_id {
+    char internal[RSSEG_RCCL_ID_BYTES];
+};
+struct rccl_api {
+    void *handle = nullptr;
+    int (*GetUniqueId)(rs_nccl_id *) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, rs_nccl_id id, int rank) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t stream) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    char path[512] = {0};
+};
+static rccl_api g_rccl;
+static std::mutex g_rccl_mu;
+
+static const char *rccl_load(const char *path)   // nullptr on success, else what failed
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return nullptr;
+    static char why[640];
+    const char *names[] = {path && *path ? path : nullptr, "librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names) {
+        if (!nm) continue;
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) { snprintf(g_rccl.path, sizeof(g_rccl.path), "%s", nm); break; }
+    }
+    if (!h) {
+        snprintf(why, sizeof(why), "dlopen(librccl) failed: %s", dlerror());
+        return why;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GetErrorString) {
+        snprintf(why, sizeof(why), "%s lacks an ncclGetUniqueId / CommInitRank / AllReduce / CommDestroy / GetErrorString symbol", g_rccl.path);
+        return why;
+    }
+    g_rccl.handle = h;
+    return nullptr;
+}
+
+static void rccl_release(rsseg_ctx *ctx)
+{
+    if (ctx->rccl_comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)g_rccl.CommDestroy(ctx->rccl_comm);
+        ctx->rccl_comm = nullptr;
+    }
+    if (ctx->own_comm_buf && ctx->d_comm) (void)hipFree(ctx->d_comm);
+    if (ctx->own_comm_buf) { ctx->d_comm = nullptr; ctx->comm_bytes = 0; ctx->own_comm_buf = false; }
+}
+
+// rsseg_allreduce_fn over the context's communicator: in place in the communication buffer, enqueued on the context's
+// stream — ordered after the kernels that left their partials there and before the kernels that read the result, no host
+// wait (the contract of include/rsseg.h).  torch's default stream reaches the library as hipStreamLegacy; RCCL is handed
+// the null stream for it, the same stream under the name torch itself passes to RCCL.
+static int rccl_allreduce(void *user, int64_t offset, int64_t count, int dtype, int op)
+{
+    rsseg_ctx *ctx = (rsseg_ctx *)user;
+    static const int types[3] = {7 /* ncclFloat32 */, 8 /* ncclFloat64 */, 4 /* ncclInt64 */};
+    static const int ops[3] = {0 /* ncclSum */, 3 /* ncclMin */, 2 /* ncclMax */};
+    if (dtype < 0 || dtype > 2 || op < 0 || op > 2 || offset < 0 || count < 0) return 1;
+    const size_t esz = dtype == RSSEG_F32 ? 4 : 8;
+    if ((size_t)offset + esz * (size_t)count > ctx->comm_bytes) return 2;
+    hipStream_t st = ctx->stream == hipStreamLegacy ? (hipStream_t) nullptr : ctx->stream;
+    void *p = ctx->d_comm + offset;
+    const int rc = g_rccl.AllReduce(p, p, (size_t)count, types[dtype], ops[op], ctx->rccl_comm, st);
+    if (rc != 0) {
+        snprintf(ctx->err, sizeof(ctx->err), "ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+        return 3;
+    }
+    return 0;
+}
+
+extern "C" int rsseg_rccl_unique_id(const char *librccl_path, void *id_out)
+{
+    if (!id_out) return RSSEG_ERR_INVALID;
+    if (const char *why = rccl_load(librccl_path)) {
+        snprintf(g_err, sizeof(g_err), "%s", why);
+        return RSSEG_ERR_COMM;
+    }
+    rs_nccl_id id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) {
+        snprintf(g_err, sizeof(g_err), "ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+        return RSSEG_ERR_COMM;
+    }
+    memcpy(id_out, id.internal, RSSEG_RCCL_ID_BYTES);
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_ctx_set_comm_rccl(rsseg_ctx *ctx, int rank, int world, const void *unique_id, const char *librccl_path, void *d_comm,
+                                       size_t comm_bytes)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world || world > RSSEG_MAX_RANKS) return rs_fail(ctx, RSSEG_ERR_INVALID, "bad rank/world %d/%d", rank, world);
+    if (!unique_id) return rs_fail(ctx, RSSEG_ERR_INVALID, "set_comm_rccl: no unique id (rank 0: rsseg_rccl_unique_id, then hand the 128 bytes to every rank)");
+    if (d_comm && comm_bytes < (1u << 20)) return rs_fail(ctx, RSSEG_ERR_INVALID, "set_comm_rccl: the communication buffer must hold >= 1 MiB");
+    if (const char *why = rccl_load(librccl_path)) return rs_fail(ctx, RSSEG_ERR_COMM, "%s", why);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rccl_release(ctx);
+    if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+    ctx->h_comm = nullptr;
+    ctx->comm_on = false;
+    ctx->allreduce = nullptr;
+    if (!d_comm) {
+        comm_bytes = (size_t)4 << 20;
+        HIPCHK(ctx, hipMalloc(&d_comm, comm_bytes));
+        HIPCHK(ctx, hipMemset(d_comm, 0, comm_bytes));
+        ctx->own_comm_buf = true;
+    }
+    ctx->d_comm = (char *)d_comm;
+    ctx->comm_bytes = comm_bytes;
+    rs_nccl_id id;
+    memcpy(id.internal, unique_id, RSSEG_RCCL_ID_BYTES);
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);     // collective: returns when all `world` ranks have called it
+    if (rc != 0 || !comm) {
+        rccl_release(ctx);
+        return rs_fail(ctx, RSSEG_ERR_COMM, "ncclCommInitRank(rank %d of %d) on %s: %s", rank, world, g_rccl.path, g_rccl.GetErrorString(rc));
+    }
+    ctx->rccl_comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    ctx->allreduce = rccl_allreduce;
+    ctx->comm_user = ctx;
+    ctx->comm_on = true;     // also with world == 1: identity reductions through RCCL (how a one-GPU box exercises this path)
+    if (hipHostMalloc((void **)&ctx->h_comm, comm_bytes, hipHostMallocDefault) != hipSuccess) {
+        rccl_release(ctx);
+        ctx->comm_on = false;
+        ctx->allreduce = nullptr;
+        return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipHostMalloc(%zu) for the communication staging buffer failed", comm_bytes);
+    }
+    return RSSEG_OK;
+}
+
 extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
 {
     if (!ctx) return;
@@ -71,6 +216,7 @@ extern "C" void rsseg_ctx_destroy(rsseg_ctx *ctx)
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_comm) (void)hipHostFree(ctx->h_comm);
+    rccl_release(ctx);
     if (ctx->d_mm) (void)hipFree(ctx->d_mm);
     if (ctx->forest.d_nodes) (void)hipFree(ctx->forest.d_nodes);
     if (ctx->forest.d_leafval) (void)hipFree(ctx->forest.d_leafval);
@@ -84,6 +230,7 @@ extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_all
                                   void *d_comm, size_t comm_bytes)
 {
     if (!ctx) return RSSEG_ERR_INVALID;
+    rccl_release(ctx);
     if (world < 1 || rank < 0 || rank >= world || world > RSSEG_MAX_RANKS)
         return rs_fail(ctx, RSSEG_ERR_INVALID, "bad rank/world %d/%d", rank, world);
     if (world > 1 && (!fn || !d_comm || comm_bytes < (1u << 20)))
@@ -102,6 +249,19 @@ extern "C" int rsseg_ctx_set_comm(rsseg_ctx *ctx, int rank, int world, rsseg_all
         if (hipHostMalloc((void **)&ctx->h_comm, comm_bytes, hipHostMallocDefault) != hipSuccess)
             return rs_fail(ctx, RSSEG_ERR_NOMEM, "hipHostMalloc(%zu) for the communication staging buffer failed", comm_bytes);
     }
+    return RSSEG_OK;
+}
+
+extern "C" int rsseg_ctx_allreduce(rsseg_ctx *ctx, int64_t offset, int64_t count, int dtype, int op)
+{
+    if (!ctx) return RSSEG_ERR_INVALID;
+    if (!ctx->comm_on) return RSSEG_OK;     // one rank, nothing installed: the identity
+    if (dtype < RSSEG_F32 || dtype > RSSEG_I64 || op < RSSEG_SUM || op > RSSEG_MAX || offset < 0 || count < 0 ||
+        (size_t)offset + (dtype == RSSEG_F32 ? 4 : 8) * (size_t)count > ctx->comm_bytes)
+        return rs_fail(ctx, RSSEG_ERR_INVALID, "allreduce: bad dtype / op / range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int rc = ctx->allreduce(ctx->comm_user, offset, count, dtype, op);
+    if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce returned %d%s%s", rc, ctx->rccl_comm ? ": " : "", ctx->rccl_comm ? ctx->err : "");
     return RSSEG_OK;
 }
 

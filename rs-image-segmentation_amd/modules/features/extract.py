@@ -1,8 +1,12 @@
 """
-Drop-in counterpart of the classification entry points of the reference's modules/features/extract.py
-that are on the hot path: unsupervised_kmeans_classification (extract.py:508-581) and
-supervised_classification_predict (extract.py:690-719).  Same signatures, same error behaviour
-(ValueError for empty / malformed inputs), NumPy in -> NumPy out.
+Drop-in counterpart of the reference's modules/features/extract.py: every function scripts/3_classification.py reaches
+through `from modules.features.extract import *` (scripts/3:25) under the reference's name, positional order, defaults,
+return dtypes and error behaviour (ValueError / FileNotFoundError), NumPy in -> NumPy out, with the per-pixel work done by
+librsseg_hip.so: KMeans (extract.py:508-581), forest inference (:690-719), the rule-based extractors (:299-505), the
+feature-file plumbing (:32-295) and the GeoTIFF writer (:778-833).  Forest TRAINING (:585-687) stays scikit-learn on the
+host, as in the reference.  The two plotting functions (:723-775, :840-) are outside the hot path: they exist so that a
+script's call resolves, print one line and draw nothing.  `__all__` at the end of the file is the star-import surface;
+tests/golden/star_import_names.json (oracle/gen_names.py) lists what the reference's scripts resolve through it.
 """
 from __future__ import annotations
 
@@ -12,9 +16,6 @@ from rsseg.runtime import default_context as _ctx
 
 import os
 import pickle
-
-__all__ = ["load_features", "normalize_features_structure", "unsupervised_kmeans_classification",
-           "supervised_classification_predict", "np", "os", "pickle"]
 
 _META_MAP = {"geo_transform": "transform", "crs": "crs", "dimensions": "dimensions", "width": "width", "height": "height",
              "transform": "transform"}
@@ -172,40 +173,59 @@ def _mask_dev(mask):
 
 
 def advanced_post_processing(binary_mask, min_area=100, smooth_kernel_size=3, fill_holes=True):
-    """extract.py:299-341: closing with the elliptical k x k element, removal of 8-connected components smaller than
-    min_area, opening with the same element.  (Even kernel sizes fall back to scipy's binary_fill_holes in the
-    reference; that branch is not reproduced: ValueError.)"""
+    """extract.py:299-341: closing with the elliptical k x k element (odd k; an even or zero k: scipy's binary_fill_holes
+    instead, :314-316), removal of 8-connected components smaller than min_area, opening with the same element (odd k only;
+    an even k prints the reference's warning and skips it, :337-338)."""
     if binary_mask is None or np.asarray(binary_mask).size == 0:
+        print("警告: 输入的二值掩码为空，后处理跳过。")
         return binary_mask
-    d, (h, w) = _mask_dev(binary_mask)
+    a = np.asarray(binary_mask)
+    if a.ndim != 2:
+        raise ValueError("advanced_post_processing expects a 2-D mask")
+    # the reference works on the mask's VALUES as uint8 (cv2 min / max filters, :306); the library's planes hold 0 / 1,
+    # which is what every caller passes (threshold masks)
+    d, (h, w) = _mask_dev(a)
     return _post(_ctx(), d, h, w, min_area, smooth_kernel_size, fill_holes).cpu().numpy().reshape(h, w)
 
 
 def _post(ctx, d, h, w, min_area, k, fill_holes=True):
     from rsseg import _lib as L
-    if k > 0 and k % 2 == 0:
-        raise ValueError("advanced_post_processing: even smooth_kernel_size (binary_fill_holes fallback) is not implemented")
-    if k not in (0, 3, 5):
-        raise ValueError("advanced_post_processing: smooth_kernel_size must be 3 or 5")
-    if fill_holes and k > 0:
-        d = ctx.morph_ellipse(d, h, w, k, L.MORPH_CLOSE)
+    odd = k > 0 and k % 2 == 1
+    if odd and k > 31:
+        from rsseg.runtime import RssegUnsupported
+        raise RssegUnsupported(f"advanced_post_processing: smooth_kernel_size {k} > 31")
+    if fill_holes and odd:
+        d = ctx.morph_ellipse(d, h, w, k, L.MORPH_CLOSE) if k > 1 else d     # a 1 x 1 element changes nothing
+    elif fill_holes:
+        d = ctx.fill_holes(d, h, w)
     if min_area > 0:
         d = ctx.remove_small_components(d, h, w, int(min_area))
-    if k > 0:
-        d = ctx.morph_ellipse(d, h, w, k, L.MORPH_OPEN)
+    if odd:
+        d = ctx.morph_ellipse(d, h, w, k, L.MORPH_OPEN) if k > 1 else d
+    elif k > 0:
+        print(f"警告: 平滑核大小 {k} 不是奇数，形态学平滑可能效果不佳或出错。")
     return d
 
 
 def threshold_segmentation(feature_image, threshold_value, above=True, otsu=False):
-    """extract.py:344-404 (otsu=False, the only form the stage uses): NaN -> 0, then > / < threshold, uint8."""
+    """extract.py:344-404: NaN -> 0, then > / < threshold -> uint8 mask; otsu=True ignores threshold_value: the plane is
+    stretched to 8 bits between its extrema and cut at cv2.threshold(THRESH_OTSU)'s level (:358-371; a plane without
+    contrast gives all 0 / all 1).  float32 planes are compared in float32, anything else in float64, as NumPy does."""
     if feature_image is None:
         raise ValueError("输入的特征图像为空。")
-    if otsu:
-        raise ValueError("threshold_segmentation: otsu=True (cv2.threshold) is not implemented")
     a = np.asarray(feature_image)
-    d = _ctx().to_device(np.ascontiguousarray(a, dtype=np.float32).reshape(-1))
-    t = float(np.float32(threshold_value)) if a.dtype == np.float32 else float(threshold_value)
-    m = _ctx().threshold_band(d, t, float("inf")) if above else _ctx().threshold_band(d, float("-inf"), t)
+    dt = np.float32 if a.dtype == np.float32 else np.float64
+    ctx = _ctx()
+    if a.size == 0:
+        return np.zeros(a.shape, np.uint8)
+    d = ctx.to_device(np.ascontiguousarray(a, dtype=dt).reshape(-1))
+    if otsu:
+        m, level, _, _ = ctx.otsu_mask(d, above)
+        if level < 0:
+            print("警告: 特征图像所有值相同，Otsu无法应用。返回全黑或全白掩码。")
+        return m.cpu().numpy().reshape(a.shape)
+    t = float(np.float32(threshold_value)) if dt == np.float32 else float(threshold_value)
+    m = ctx.threshold_band(d, t, float("inf")) if above else ctx.threshold_band(d, float("-inf"), t)
     return m.cpu().numpy().reshape(a.shape)
 
 
@@ -329,3 +349,130 @@ def rule_based_classification(features):
     ctx.mask_paint(final, bare, 4, only_unset=True)
     return final.cpu().numpy().reshape(h, w)
 
+
+# --------------------------------------------------------------------------------------------------
+# forest training helpers (reference extract.py:585-687): host-side scikit-learn, as in the reference — fitting is not
+# on the accelerated path; inference with the fitted model is (supervised_classification_predict above)
+# --------------------------------------------------------------------------------------------------
+def prepare_training_samples(feature_array, labeled_roi_path):
+    """extract.py:585-633: rows of the (H, W, F) stack under the non-zero pixels of a single-band label raster
+    (read with rsseg.tiff instead of rasterio) -> (X, y); NaN features -> 0."""
+    if not os.path.exists(labeled_roi_path):
+        raise FileNotFoundError(f"标签ROI文件未找到: {labeled_roi_path}")
+    if feature_array is None or getattr(feature_array, "ndim", 0) != 3:
+        raise ValueError("输入的feature_array必须是3D NumPy数组 (height, width, n_features)。")
+    from rsseg.tiff import read_tiff
+    h, w, f = feature_array.shape
+    labels = read_tiff(labeled_roi_path)[0]
+    if labels.shape != (h, w):
+        raise ValueError(f"标签ROI文件 '{labeled_roi_path}' (形状 {labels.shape}) 尺寸与特征数据 (期望的2D形状 {(h, w)}) 不匹配。")
+    flat = labels.reshape(-1)
+    keep = np.flatnonzero((flat != 0) & ~np.isnan(flat))
+    if keep.size == 0:
+        raise ValueError("未能从ROI中提取任何有效的训练样本。请检查标签ROI文件和类别定义。")
+    X = feature_array.reshape(-1, f)[keep, :]
+    if np.isnan(X).any():
+        print("警告: 提取的训练样本中存在NaN值，将用0填充。")
+        X = np.nan_to_num(X, nan=0.0)
+    return X, flat[keep]
+
+
+def train_random_forest_classifier(X_train, y_train, feature_names_for_training, n_estimators=100, test_size=0.3, random_state=42):
+    """extract.py:635-687: stratified 70 / 30 split (when every class has two samples), RandomForestClassifier(n_estimators,
+    random_state, n_jobs=-1).fit, validation accuracy / kappa / importances printed.  Returns the fitted classifier."""
+    from sklearn.ensemble import RandomForestClassifier
+    from sklearn.metrics import accuracy_score, classification_report, cohen_kappa_score
+    from sklearn.model_selection import train_test_split
+    classes, counts = np.unique(y_train, return_counts=True)
+    stratify = y_train if len(classes) > 1 and counts.min() >= 2 else None
+    if len(classes) > 1 and stratify is None:
+        print(f"警告: 部分类别样本数少于2个 ({dict(zip(classes, counts))})。训练/验证分割时这些类别可能无法进行分层抽样。")
+    X_t, X_val, y_t, y_val = train_test_split(X_train, y_train, test_size=test_size, random_state=random_state, stratify=stratify)
+    print(f"训练样本数: {X_t.shape[0]}, 验证样本数: {X_val.shape[0]}")
+    if X_t.shape[0] == 0:
+        raise ValueError("没有足够的训练样本进行分割。")
+    clf = RandomForestClassifier(n_estimators=n_estimators, random_state=random_state, n_jobs=-1)
+    clf.fit(X_t, y_t)
+    if X_val.shape[0] == 0:
+        print("警告: 验证样本数为0，跳过验证评估。")
+        return clf
+    pred = clf.predict(X_val)
+    print(f"随机森林分类器验证集性能:\n  准确率: {accuracy_score(y_val, pred):.4f}\n  Kappa系数: {cohen_kappa_score(y_val, pred):.4f}")
+    print(classification_report(y_val, pred, labels=np.unique(np.concatenate((y_val, pred))), zero_division=0))
+    imp = clf.feature_importances_
+    if len(feature_names_for_training) == imp.size:
+        for i in np.argsort(imp)[::-1]:
+            print(f"    特征 '{feature_names_for_training[i]}': {imp[i]:.4f}")
+    else:
+        print("\n警告: 特征重要性无法显示。特征名称数量与分类器的特征重要性数组大小不匹配。")
+    return clf
+
+
+# --------------------------------------------------------------------------------------------------
+# output (reference extract.py:778-833) and the plotting names (out of scope: SURVEY.md §2)
+# --------------------------------------------------------------------------------------------------
+def save_classification_as_geotiff(classification_result, features_meta, output_tif_path):
+    """extract.py:778-833: one band, nodata 0, LZW in 256 x 256 tiles; uint8 when the labels fit, else uint16, else int32;
+    float labels are rounded.  An empty result, incomplete metadata ('transform', 'crs', 'width', 'height'), a shape that
+    contradicts the metadata or a write error are reported with print and the function returns None, like the reference.
+    The file is written by rsseg.tiff (rasterio / GDAL are not needed)."""
+    if classification_result is None or np.asarray(classification_result).size == 0:
+        print("分类结果为空，无法保存为GeoTIFF。")
+        return
+    if not all(k in features_meta and features_meta[k] is not None for k in ("transform", "crs", "width", "height")):
+        print("警告: 用于保存GeoTIFF的元数据不完整。需要 'transform', 'crs', 'width', 'height'。")
+        print(f"可用的元数据键: {list(features_meta.keys())}")
+        return
+    try:
+        a = np.asarray(classification_result)
+        if a.max() <= 255 and a.min() >= 0:
+            dt = np.uint8
+        elif a.max() <= 65535 and a.min() >= 0:
+            dt = np.uint16
+        else:
+            dt = np.int32
+        if np.issubdtype(a.dtype, np.floating):
+            print("警告: 分类结果包含浮点数标签，将转换为整数。")
+            a = np.round(a).astype(dt)
+        else:
+            a = a.astype(dt)
+        if a.ndim != 2 or a.shape[0] != features_meta["height"] or a.shape[1] != features_meta["width"]:
+            print(f"Warning: Classification result shape {a.shape} does not match dimensions in metadata "
+                  f"({features_meta['height']}, {features_meta['width']}). Skipping GeoTIFF save.")
+            return
+        from rsseg.stages import _epsg_of, _is_geographic
+        from rsseg.tiff import write_tiff
+        crs = features_meta["crs"]
+        write_tiff(output_tif_path, a, transform=features_meta["transform"], epsg=_epsg_of(crs), geographic=_is_geographic(crs),
+                   nodata=0, compress="lzw", tiled=True)
+        print(f"分类结果已保存为GeoTIFF: {output_tif_path}")
+    except Exception as e:  # noqa: BLE001 — extract.py:832-833 prints and returns
+        print(f"保存GeoTIFF文件 '{output_tif_path}' 时出错: {e}")
+
+
+def create_classification_map(classification_result, class_names_map, class_colors_map, save_path="classification_map.png", title="地物分类图"):
+    """extract.py:723-775 draws a PNG with matplotlib: plotting is outside this path.  Kept as a name so that
+    scripts/3:493 resolves; writes nothing."""
+    print(f"[rsseg] create_classification_map: plotting is out of scope, '{save_path}' not written")
+
+
+def visualize_combined_indices(features_dict, output_dir="visualization_outputs", save_path="combined_indices_map.png"):
+    """extract.py:840- (matplotlib figure): plotting is outside this path; kept as a name (scripts/3:613), writes nothing."""
+    print(f"[rsseg] visualize_combined_indices: plotting is out of scope, '{os.path.join(output_dir, save_path)}' not written")
+
+
+PLOTTING_NAMES = ("create_classification_map", "visualize_combined_indices")   # resolve, draw nothing
+
+# The star-import surface (scripts/3_classification.py:25).  The reference module has no __all__, so its import * also
+# leaks its library imports; of those the script uses np, os, pickle (scripts/3:43, 145, 598) — and cv2 on one defensive
+# line (:351, a mask of the wrong shape), which is not re-exported: cv2 is not a dependency of this implementation.
+__all__ = [
+    "load_features", "normalize_features_structure",
+    "advanced_post_processing", "threshold_segmentation",
+    "extract_vegetation_by_threshold", "extract_water_by_threshold", "extract_builtup_by_threshold", "extract_bareland_by_rule",
+    "rule_based_classification",
+    "unsupervised_kmeans_classification",
+    "prepare_training_samples", "train_random_forest_classifier", "supervised_classification_predict",
+    "create_classification_map", "save_classification_as_geotiff", "visualize_combined_indices",
+    "np", "os", "pickle",
+]

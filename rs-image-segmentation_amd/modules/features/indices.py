@@ -9,6 +9,8 @@ are out of scope; every member of the stage-2 featur
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from rsseg import _lib as _L
@@ -20,7 +22,7 @@ __all__ = [
     "robust_normalize", "calculate_ndvi", "calculate_evi", "calculate_msavi", "calculate_ndwi", "calculate_mndwi",
     "calculate_ndbi", "calculate_bsi", "perform_pca", "calculate_glcm_features", "calculate_lbp_features", "calculate_morphological_features",
     "calculate_multi_scale_features", "calculate_filter_responses", "add_spatial_context", "prepare_level_1_features",
-    "prepare_level_2_features", "np",
+    "prepare_level_2_features", "visualize_hierarchical_features", "visualize_selected_features", "np", "os",
 ]
 
 
@@ -250,3 +252,17 @@ def prepare_level_2_features(features_dict):
     if "filter_features" in features_dict and "sobel_mag" in features_dict["filter_features"]:
         level.append(features_dict["filter_features"]["sobel_mag"])
     return np.stack(level, axis=-1) if level else np.zeros((1, 1, 1))
+
+
+def visualize_hierarchical_features(hierarchical_features, features_dict):
+    """indices.py:867- (matplotlib figures): plotting is outside this path.  Kept as a name so that
+    scripts/2_feature_extraction.py:131 resolves; draws nothing."""
+    print("[rsseg] visualize_hierarchical_features: plotting is out of scope, nothing drawn")
+
+
+def visualize_selected_features(features_dict, max_features=12, save_path="selected_features_visualization.png"):
+    """indices.py:564-628 (matplotlib figure): plotting is outside this path; kept as a name, writes nothing."""
+    print(f"[rsseg] visualize_selected_features: plotting is out of scope, '{save_path}' not written")
+
+
+PLOTTING_NAMES = ("visualize_hierarchical_features", "visualize_selected_features")   # resolve, draw nothing

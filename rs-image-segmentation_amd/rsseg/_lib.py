@@ -103,6 +103,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_double), C.POINTER(KMeansInfo)]),
     "rsseg_kmeans_fit_predict_mm": (_int, [_vp, _PP, _int, _int, _i64, _int, C.c_uint32, _int, C.c_double, _vp,
                                            C.POINTER(C.c_double), C.POINTER(KMeansInfo), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rsseg_ctx_allreduce": (_int, [_vp, _i64, _i64, _int, _int]),
+    "rsseg_rccl_unique_id": (_int, [C.c_char_p, _vp]),
+    "rsseg_ctx_set_comm_rccl": (_int, [_vp, _int, _int, _vp, C.c_char_p, _vp, C.c_size_t]),
     "rsseg_ctx_collect_minmax": (_int, [_vp, _int]),
     "rsseg_ctx_last_minmax": (_int, [_vp, _int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rsseg_forest_load": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -111,6 +114,9 @@ SIGNATURES = {
     "rsseg_forest_predict": (_int, [_vp, _PP, _int, _i64, _vp]),
     "rsseg_threshold_band_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _vp]),
     "rsseg_band_interval_f32": (_int, [_vp, _vp, _i64, C.c_float, C.c_float, _int, _vp]),
+    "rsseg_band_interval_f64": (_int, [_vp, _vp, _i64, C.c_double, C.c_double, _int, _vp]),
+    "rsseg_otsu_mask": (_int, [_vp, _vp, _int, _i64, _int, _vp, C.POINTER(_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rsseg_fill_holes_u8": (_int, [_vp, _vp, _int, _int, _vp]),
     "rsseg_mask_op_u8": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "rsseg_mask_paint_u8": (_int, [_vp, _vp, _vp, _i64, _int, _int]),
     "rsseg_morph_ellipse_u8": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),

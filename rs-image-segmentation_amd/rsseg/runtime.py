@@ -73,10 +73,15 @@ class Context:
     """Owns an rsseg_ctx.  `group` (optional) is a torch.distributed process group: when its world
     size is > 1 the library's reductions go through RCCL (or gloo in CPU tests of the hook)."""
 
-    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None, stream=None, force_comm: bool = False):
+    def __init__(self, device: int = 0, group=None, use_dist: Optional[bool] = None, stream=None, force_comm: bool = False,
+                 comm: Optional[str] = None):
         """stream: a torch.cuda.Stream for this context (default: torch's current stream).
-        force_comm: install the all-reduce hook even when the group has ONE rank (identity reductions), so that every
-        collective of a step runs through the backend — the way to exercise the RCCL path on a one-GPU box."""
+        force_comm: install the all-reduce path even when the group has ONE rank (identity reductions), so that every
+        collective of a step runs through the backend — the way to exercise the RCCL path on a one-GPU box.
+        comm: 'native' — the library drives RCCL itself (rsseg_ctx_set_comm_rccl: its own communicator, ncclAllReduce on the
+        context's stream, no Python in the loop; torch.distributed only carries the 128-byte unique id once); 'torch' — the
+        callback into torch.distributed.all_reduce.  Default ($RSSEG_COMM overrides): 'native' when the group's backend is
+        nccl (= RCCL), 'torch' otherwise (gloo rehearsals)."""
         torch = _torch()
         self.lib = L.load()
         if not torch.cuda.is_available():
@@ -101,8 +106,16 @@ class Context:
             use_dist = dist.is_available() and dist.is_initialized()
         if force_comm and not use_dist:
             raise RssegError("force_comm needs an initialised torch.distributed process group")
+        self.comm_kind = None
         if use_dist and (dist.get_world_size(group) > 1 or force_comm):
-            self._install_comm(group)
+            kind = comm or os.environ.get("RSSEG_COMM") or ("native" if dist.get_backend(group) == "nccl" else "torch")
+            if kind not in ("native", "torch"):
+                raise ValueError(f"comm={kind!r}: 'native' or 'torch'")
+            if kind == "native":
+                self._install_comm_rccl(group)
+            else:
+                self._install_comm(group)
+            self.comm_kind = kind
 
     # ---- communication hook ----------------------------------------------------------------
     def _install_comm(self, group):
@@ -113,6 +126,34 @@ class Context:
         self._hook = L.ALLREDUCE_FN(make_allreduce_hook(self._comm_buf, group, self.torch_stream))
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
+
+    def _install_comm_rccl(self, group):
+        """RCCL driven from C: rank 0 makes the ncclUniqueId, torch.distributed hands its 128 bytes to the other ranks (the
+        only use of the process group), every rank joins the library's own communicator."""
+        torch = _torch()
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        cpath = path.encode() if os.path.exists(path) else None
+        box = [None]
+        if self.rank == 0:
+            raw = (C.c_char * 128)()
+            rc = self.lib.rsseg_rccl_unique_id(cpath, C.cast(raw, C.c_void_p))
+            if rc != 0:
+                raise RssegError(f"rsseg_rccl_unique_id failed ({rc}): {self.lib.rsseg_last_error(None).decode()}")
+            box[0] = bytes(raw.raw)
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = (C.c_char * 128).from_buffer_copy(box[0])
+        self._comm_buf = torch.zeros(1 << 22, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self._chk(self.lib.rsseg_ctx_set_comm_rccl(self.h, self.rank, self.world, C.cast(uid, C.c_void_p), cpath,
+                                                   C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
+
+    def allreduce(self, offset: int, count: int, dtype: int, op: int):
+        """One in-place reduction of `count` elements at byte `offset` of the communication buffer (self._comm_buf) over the
+        installed path, enqueued on this context's stream (rsseg_ctx_allreduce)."""
+        self._chk(self.lib.rsseg_ctx_allreduce(self.h, offset, count, dtype, op))
 
     def install_comm_hook(self, rank: int, world: int, hook):
         """A caller-supplied all-reduce instead of torch.distributed: hook(buf, offset, count, dtype, op) -> None reduces
@@ -563,8 +604,31 @@ class Context:
         False: a NaN pixel is outside every interval (the plain comparisons of extract_bareland_by_rule, extract.py:486-497)."""
         torch = _torch()
         out = self.empty(plane.numel(), torch.uint8)
+        if plane.dtype == torch.float64:
+            self._chk(self.lib.rsseg_band_interval_f64(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_double(lo), C.c_double(hi),
+                                                       int(nan_as_zero), C.c_void_p(out.data_ptr())))
+            return out
         self._chk(self.lib.rsseg_band_interval_f32(self.h, C.c_void_p(plane.data_ptr()), plane.numel(), C.c_float(lo), C.c_float(hi),
                                                    int(nan_as_zero), C.c_void_p(out.data_ptr())))
+        return out
+
+    def otsu_mask(self, plane, above: bool = True):
+        """threshold_segmentation(..., otsu=True) (extract.py:358-371) of a float32 / float64 plane -> (uint8 mask, level or -1
+        when the plane has no contrast, min, max)."""
+        torch = _torch()
+        if plane.dtype not in (torch.float32, torch.float64):
+            raise ValueError("otsu_mask: float32 or float64 plane expected")
+        out = self.empty(plane.numel(), torch.uint8)
+        level, mn, mx = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._chk(self.lib.rsseg_otsu_mask(self.h, C.c_void_p(plane.data_ptr()), L.F32 if plane.dtype == torch.float32 else L.F64,
+                                           plane.numel(), int(bool(above)), C.c_void_p(out.data_ptr()), C.byref(level), C.byref(mn), C.byref(mx)))
+        return out, level.value, mn.value, mx.value
+
+    def fill_holes(self, mask, H: int, W: int):
+        """scipy.ndimage.binary_fill_holes of a 0 / 1 uint8 plane (extract.py:314-316)."""
+        torch = _torch()
+        out = self.empty(H * W, torch.uint8)
+        self._chk(self.lib.rsseg_fill_holes_u8(self.h, C.c_void_p(mask.data_ptr()), H, W, C.c_void_p(out.data_ptr())))
         return out
 
     def mask_op(self, a, b, op: int):

@@ -117,18 +117,11 @@ def _is_geographic(crs) -> Optional[bool]:
 
 
 def save_class_map_tif(class_map: np.ndarray, out_tif: str, transform=None, crs=None) -> str:
-    """save_classification_as_geotiff (reference modules/features/extract.py:778-833): one band, nodata 0, LZW in
-    256 x 256 tiles; uint8 when the labels fit, else uint16, else int32; float labels are rounded."""
-    from .tiff import write_tiff
+    """Convenience form of modules.features.extract.save_classification_as_geotiff (reference extract.py:778-833) for callers
+    that hold transform / crs instead of a feature dictionary."""
+    from modules.features.extract import save_classification_as_geotiff
     a = np.asarray(class_map)
-    if a.size and a.max() <= 255 and a.min() >= 0:
-        dt = np.uint8
-    elif a.size and a.max() <= 65535 and a.min() >= 0:
-        dt = np.uint16
-    else:
-        dt = np.int32
-    a = np.round(a).astype(dt) if np.issubdtype(a.dtype, np.floating) else a.astype(dt)
-    write_tiff(out_tif, a, transform=transform, epsg=_epsg_of(crs), geographic=_is_geographic(crs), nodata=0, compress="lzw", tiled=True)
+    save_classification_as_geotiff(a, {"transform": transform, "crs": crs, "height": a.shape[0], "width": a.shape[1]}, out_tif)
     return out_tif
 
 
@@ -147,7 +140,8 @@ RF_MODEL_FILE = "random_forest_model.joblib"   # scripts/3_classification.py:459
 
 
 def run_classification_stage(feature_file_path, method='rule_based', output_dir="segmentation_outputs", use_hierarchical_all=True, *,
-                             n_clusters: int = 7, classifier=None, feature_keys=None, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
+                             n_clusters: int = 7, classifier=None, feature_keys=None, labeled_roi_file: str = "labeled_roi.tif",
+                             strict_reference: bool = False, ctx: Optional[Context] = None) -> Optional[np.ndarray]:
     """run_classification_stage (scripts/3_classification.py:267-505): the reference's name, positional order and defaults
     (`method='rule_based'`, `output_dir="segmentation_outputs"`, `use_hierarchical_all=True`); what follows the `*` are
     keyword-only additions.  Loads and normalises the feature file (extract.py:32-295), dispatches on `method`:
@@ -160,13 +154,15 @@ def run_classification_stage(feature_file_path, method='rule_based', output_dir=
                        SURVEY.md 3.2); the reference then announces "将使用自动选择" (automatic selection) but hands over the
                        EMPTY list, on which unsupervised_kmeans_classification raises (extract.py:533).  This driver does what
                        the message says: `feature_keys_to_use=None`, i.e. every 2-D plane of the dictionary (55 on a stage-2
-                       pickle).  `feature_keys` overrides the selection.
+                       pickle).  `feature_keys` overrides the selection; `strict_reference=True` hands over the empty list
+                       as the reference does, i.e. raises its ValueError.
       'random_forest'  scripts/3:401-488, inference part: the feature array is 'hierarchical_all' (also under stage 2's key
                        'hierarchical_features_all') when `use_hierarchical_all`, else every 2-D plane of the image's shape
                        stacked (:425-437); the classifier is `classifier` when given, else <output_dir>/random_forest_model.joblib
-                       when it exists and its n_features_in_ matches (:459-475).  Training (prepare_training_samples +
-                       train_random_forest_classifier, :450-475) is outside the hot path: without a usable model the stage reports
-                       that and returns None.
+                       when it exists and its n_features_in_ matches (:459-475); otherwise the forest is fitted on the host from
+                       `labeled_roi_file` (prepare_training_samples + train_random_forest_classifier, :450-475, scikit-learn as in
+                       the reference) and cached as that joblib file.  Without a model and without the label raster the stage
+                       reports that and returns None (the reference insists on the label raster even when the cache exists, :405-409).
 
     Writes <output_dir>/classification_<method>.npy and, when the feature file carries transform / crs / width / height
     (scripts/3:495-498), <output_dir>/<method>_classification_map.tif (uint8 labels, nodata 0, LZW tiles); the PNG of
@@ -192,12 +188,32 @@ def run_classification_stage(feature_file_path, method='rule_based', output_dir=
     except Exception as e:  # noqa: BLE001 — scripts/3:307-311 prints and returns
         print(f"加载或规范化特征失败: {e}")
         return None
-    shape = (feats["height"], feats["width"])
-    if ctx is not None:   # the mirrors run on the process-wide context
-        from . import runtime as _rt
+    from . import runtime as _rt
+    prev_ctx = _rt._default_ctx
+    if ctx is not None:   # the mirrors run on the process-wide context: lend them this one for the duration of the call
         _rt._default_ctx = ctx
+    try:
+        out = _classify(feats, method, output_dir, use_hierarchical_all, n_clusters, classifier, feature_keys, labeled_roi_file,
+                        strict_reference)
+    finally:
+        _rt._default_ctx = prev_ctx
+    if out is None:
+        return None
+    from modules.features.extract import save_classification_as_geotiff
+    np.save(os.path.join(output_dir, f"classification_{method}.npy"), out)
+    if all(feats.get(k) is not None for k in ("transform", "crs", "width", "height")):   # scripts/3:495-498
+        save_classification_as_geotiff(out, feats, os.path.join(output_dir, f"{method}_classification_map.tif"))
+    else:
+        print("警告: 元数据不完整，无法将分类结果保存为带地理参考的GeoTIFF。")
+    return out
+
+
+def _classify(feats, method, output_dir, use_hierarchical_all, n_clusters, classifier, feature_keys, labeled_roi_file, strict_reference):
+    """The dispatch of scripts/3_classification.py:335-488 on a normalised feature dictionary -> label map or None."""
+    from modules.features.extract import (prepare_training_samples, rule_based_classification, supervised_classification_predict,
+                                          train_random_forest_classifier, unsupervised_kmeans_classification)
+    shape = (feats["height"], feats["width"])
     if method == "rule_based":
-        from modules.features.extract import rule_based_classification
         rules = {}
         for k in ("ndvi", "ndwi", "mndwi", "ndbi"):
             v = feats.get(k)
@@ -206,51 +222,60 @@ def run_classification_stage(feature_file_path, method='rule_based', output_dir=
             if v is not None:
                 rules[k] = v
         rules["height"], rules["width"] = shape
-        out = rule_based_classification(rules)
-    elif method == "kmeans":
+        return rule_based_classification(rules)
+    if method == "kmeans":
         wanted = ["ndvi", "ndwi", "ndbi", "texture_mean", "hierarchical_all"] if feature_keys is None else list(feature_keys)
         valid = [k for k in wanted if isinstance(feats.get(k), np.ndarray) and feats[k].ndim in (2, 3)]
         if not valid:
             print(f"警告: 为KMeans指定的特征键 {wanted} 在数据中均不可用，将使用自动选择。")
-        out = (unsupervised_kmeans_classification(feats, n_clusters, valid or None) + 1).astype(np.uint8)   # scripts/3:394
-    elif method in ("random_forest", "rf", "supervised"):
-        from modules.features.extract import supervised_classification_predict
-        arr = None
+        keys = valid if (valid or strict_reference) else None      # the reference passes [] and raises (scripts/3:391, extract.py:533)
+        return (unsupervised_kmeans_classification(feats, n_clusters, keys) + 1).astype(np.uint8)   # scripts/3:394
+    if method in ("random_forest", "rf", "supervised"):
+        arr, names = None, []
         if use_hierarchical_all:
             for key in ("hierarchical_all", "hierarchical_features_all"):
                 v = feats.get(key)
                 if isinstance(v, np.ndarray) and v.ndim == 3 and v.shape[:2] == shape:
                     arr = v
+                    names = [f"hierarchical_feature_{i + 1}" for i in range(v.shape[-1])]
                     break
         if arr is None:   # scripts/3:425-437: every 2-D plane of the image's shape, in dict order
-            keys = [k for k, v in feats.items() if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == shape]
-            if not keys:
+            names = [k for k, v in feats.items() if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape == shape]
+            if not names:
                 print("错误: 为随机森林指定的特征键在数据中均不可用或不是匹配图像形状的2D数组。")
                 return None
-            arr = np.stack([feats[k] for k in keys], axis=-1)
+            arr = np.stack([feats[k] for k in names], axis=-1)
         model_path = os.path.join(output_dir, RF_MODEL_FILE)
-        if classifier is None and os.path.exists(model_path):
+        try:
             import joblib
-            print(f"加载已训练的随机森林模型: {model_path}")
-            classifier = joblib.load(model_path)
-        if classifier is None:
-            print(f"错误: 没有可用的随机森林模型 ('{model_path}' 不存在, 未传入 classifier)；训练不在本实现范围内。")
+            if classifier is None and os.path.exists(model_path):
+                print(f"加载已训练的随机森林模型: {model_path}")
+                classifier = joblib.load(model_path)
+            nf = getattr(classifier, "n_features_in_", None)
+            if classifier is not None and nf is not None and nf != arr.shape[-1]:
+                print(f"警告: 加载的分类器需要 {nf} 个特征，但准备的数据有 {arr.shape[-1]} 个。正在重新训练模型。")
+                classifier = None
+            if classifier is None:      # scripts/3:450-475: fit on the host from the label raster, cache the model
+                if not os.path.exists(labeled_roi_file):
+                    print(f"错误: 监督分类所需的标签ROI文件 '{labeled_roi_file}' 未找到 (也没有可用的模型 '{model_path}')。")
+                    return None
+                X, y = prepare_training_samples(arr, labeled_roi_file)
+                classifier = train_random_forest_classifier(X, y, feature_names_for_training=names)
+                joblib.dump(classifier, model_path)
+                print(f"随机森林模型训练并保存至: {model_path}")
+            return supervised_classification_predict(arr, classifier)
+        except _rt_unsupported():
+            raise
+        except Exception as e:  # noqa: BLE001 — scripts/3:482-486 prints and returns
+            print(f"随机森林分类过程中发生错误: {e}")
             return None
-        nf = getattr(classifier, "n_features_in_", None)
-        if nf is not None and nf != arr.shape[-1]:
-            print(f"警告: 加载的分类器需要 {nf} 个特征，但准备的数据有 {arr.shape[-1]} 个；重新训练不在本实现范围内。")
-            return None
-        out = supervised_classification_predict(arr, classifier)
-    else:
-        print(f"错误: 不支持的分割方法 '{method}'")
-        return None
-    np.save(os.path.join(output_dir, f"classification_{method}.npy"), out)
-    if all(feats.get(k) is not None for k in ("transform", "crs", "width", "height")):
-        if out.shape == shape:
-            save_class_map_tif(out, os.path.join(output_dir, f"{method}_classification_map.tif"), feats["transform"], feats["crs"])
-    else:
-        print("警告: 元数据不完整，无法将分类结果保存为带地理参考的GeoTIFF。")
-    return out
+    print(f"错误: 不支持的分割方法 '{method}'")
+    return None
+
+
+def _rt_unsupported():
+    from .runtime import RssegUnsupported
+    return RssegUnsupported
 
 
 # --------------------------------------------------------------------------------------------------

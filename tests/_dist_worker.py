@@ -121,13 +121,40 @@ def main():
             got = buf[:80].view(torch.int64) + 1
         side.synchronize()
         assert got.tolist() == [16 + i for i in range(10)], got.tolist()
+        # (1b) the same ordering test for RCCL driven by the library itself (rsseg_ctx_set_comm_rccl: ncclAllReduce on the
+        # context's stream), on a context that lives on the side stream
+        nctx = Context(0, use_dist=True, force_comm=True, comm="native", stream=side)
+        assert nctx.comm_kind == "native" and nctx.world == 1
+        nbuf = nctx._comm_buf
+        with torch.cuda.stream(side):
+            big.add_(4)
+            nbuf[256:336].view(torch.int64).copy_(big[:10] * 3 + torch.arange(10, device="cuda"))
+        nctx.allreduce(256, 10, L.I64, L.SUM)                   # enqueued behind the writer, no host wait
+        with torch.cuda.stream(side):
+            got = nbuf[256:336].view(torch.int64) * 2
+        side.synchronize()
+        assert got.tolist() == [2 * (21 + i) for i in range(10)], got.tolist()
+        for dt, view, op, vals in ((L.F64, torch.float64, L.MAX, [-1.5, 2.25, 1e300]), (L.F64, torch.float64, L.MIN, [3.0, -0.0, 7.5]),
+                                   (L.F32, torch.float32, L.SUM, [0.1, 0.2, 0.3])):
+            esz = 4 if dt == L.F32 else 8
+            with torch.cuda.stream(side):
+                nbuf[:3 * esz].view(view).copy_(torch.tensor(vals, dtype=view))
+            nctx.allreduce(0, 3, dt, op)
+            side.synchronize()
+            assert nbuf[:3 * esz].view(view).tolist() == torch.tensor(vals, dtype=view).tolist()
+        try:
+            nctx.allreduce(nbuf.numel() - 8, 2, L.I64, L.SUM)   # past the end of the buffer
+            raise AssertionError("a range beyond the communication buffer was accepted")
+        except ValueError:
+            pass
+        nctx.close()
         data = np.load(os.path.join(outdir, "input.npz"))
         bands = data["bands"]
         H, W = bands.shape[1:]
         res = []
-        for force in (False, True):
-            ctx = Context(0, use_dist=True, force_comm=force)
-            assert ctx.world == 1
+        for force, kind in ((False, None), (True, "torch"), (True, "native")):
+            ctx = Context(0, use_dist=True, force_comm=force, comm=kind)
+            assert ctx.world == 1 and ctx.comm_kind == kind
             ctx.prof_enable(True)
             dev = [ctx.to_device(bands[i].reshape(-1)) for i in range(bands.shape[0])]
             labels, meta, planes = P.config3(ctx, dev, H, W, int(data["k"]))
@@ -140,13 +167,15 @@ def main():
             res.append(dict(labels=labels.cpu().numpy(), centers=meta["centers"], n_iter=meta["n_iter"], init=meta["init_indices"],
                             planes=[p.cpu().numpy() for p in planes], st=[p.cpu().numpy() for p in st], fl=fl.cpu().numpy(), calls=calls))
             ctx.close()
-        a, b = res
-        assert a["calls"] == 0 and b["calls"] >= 20, (a["calls"], b["calls"])
-        assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["centers"], b["centers"])
-        assert a["n_iter"] == b["n_iter"] and np.array_equal(a["init"], b["init"])
-        for x, y in zip(a["planes"] + a["st"], b["planes"] + b["st"]):
-            assert np.array_equal(x, y, equal_nan=True)
-        assert np.array_equal(a["fl"], b["fl"])
+        a = res[0]
+        assert a["calls"] == 0
+        for b in res[1:]:      # through torch.distributed's RCCL, then through the library's own communicator
+            assert b["calls"] >= 20 and b["calls"] == res[1]["calls"], (a["calls"], b["calls"])
+            assert np.array_equal(a["labels"], b["labels"]) and np.array_equal(a["centers"], b["centers"])
+            assert a["n_iter"] == b["n_iter"] and np.array_equal(a["init"], b["init"])
+            for x, y in zip(a["planes"] + a["st"], b["planes"] + b["st"]):
+                assert np.array_equal(x, y, equal_nan=True)
+            assert np.array_equal(a["fl"], b["fl"])
         open(os.path.join(outdir, "ok_rccl"), "w").write(str(b["calls"]))
     dist.destroy_process_group()
 

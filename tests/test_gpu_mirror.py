@@ -232,6 +232,45 @@ def test_classification_stage_forest_branch_loads_the_joblib_model(ctx, crop, tm
     assert np.array_equal(stages.run_classification_stage(paths["pkl"], "random_forest", str(tmp_path / "kw"), classifier=m19), got)
 
 
+def test_classification_stage_forest_branch_trains_from_a_label_raster(ctx, crop, tmp_path):
+    """scripts/3:450-475: without a cached model the forest is fitted from the label raster (prepare_training_samples +
+    train_random_forest_classifier, host scikit-learn as in the reference), cached as random_forest_model.joblib, and
+    the map is the fitted model's prediction — computed by the forest kernel."""
+    import joblib
+    from modules.features import extract as E
+    from rsseg import stages
+    from rsseg.tiff import write_tiff
+    fd, hier = stages.run_feature_extraction_stage(list(crop["bands"]))
+    paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 96, 96)
+    roi = np.zeros((96, 96), np.uint8)
+    ndvi = fd["ndvi"]
+    roi[8:40, 8:40] = np.where(ndvi[8:40, 8:40] > np.median(ndvi), 1, 2)
+    roi[60:90, 50:90] = 3
+    write_tiff(str(tmp_path / "roi.tif"), roi)
+    X, y = E.prepare_training_samples(hier["all"], str(tmp_path / "roi.tif"))
+    keep = roi.reshape(-1) != 0
+    assert np.array_equal(X, hier["all"].reshape(-1, 19)[keep]) and np.array_equal(y, roi.reshape(-1)[keep])
+    with pytest.raises(FileNotFoundError):
+        E.prepare_training_samples(hier["all"], str(tmp_path / "nope.tif"))
+    with pytest.raises(ValueError):
+        E.prepare_training_samples(hier["all"][:50], str(tmp_path / "roi.tif"))
+    out_dir = tmp_path / "rf_train"
+    got = stages.run_classification_stage(paths["pkl"], "random_forest", str(out_dir), labeled_roi_file=str(tmp_path / "roi.tif"))
+    model = joblib.load(out_dir / stages.RF_MODEL_FILE)
+    assert model.n_features_in_ == 19 and set(model.classes_) == {1, 2, 3}
+    assert got.shape == (96, 96) and np.array_equal(got, model.predict(hier["all"].reshape(-1, 19)).reshape(96, 96))
+    again = stages.run_classification_stage(paths["pkl"], "random_forest", str(out_dir))      # the cached model, no label raster needed
+    assert np.array_equal(again, got)
+    # the reference's own KMeans call on a stage-2 pickle hands over the empty key list and raises (scripts/3:391, extract.py:533)
+    with pytest.raises(ValueError):
+        stages.run_classification_stage(paths["pkl"], "kmeans", str(tmp_path / "strict"), strict_reference=True)
+    # the context lent to the stage is handed back afterwards
+    from rsseg import runtime as rt
+    before = rt._default_ctx
+    stages.run_classification_stage(paths["pkl"], "rule_based", str(tmp_path / "lend"), ctx=ctx)
+    assert rt._default_ctx is before
+
+
 def test_kmeans_default_key_selection_equals_the_reference_on_55_planes(ctx, golden_dir, oracle):
     """The DEFAULT call of unsupervised_kmeans_classification (feature_keys_to_use=None, extract.py:516-522): every 2-D
     plane of a stage-2-shaped dictionary, 55 float32 / float64 planes -> a float64 matrix.  The labels were produced by the
@@ -445,6 +484,101 @@ def test_rule_based_classification_vs_oracle(ctx, scene, oracle, tmp_path):
     paths = stages.save_feature_outputs(str(tmp_path), fd, hier, 600, 600)
     out = stages.run_classification_stage(paths["pkl"], "rule_based", str(tmp_path / "cls"))
     assert np.array_equal(out, want)
+
+
+def test_rule_based_branch_through_star_import_names(ctx, scene, oracle):
+    """The rule-based branch as scripts/3_classification.py:338-375 writes it, with every name taken from
+    `from modules.features.extract import *` (scripts/3:25): the three extractors with the script's thresholds and minimum
+    areas, the priority merge, extract_bareland_by_rule on the merged map's classes — equal to the oracle's restatement of
+    the same branch and to the fused device form rule_based_classification."""
+    ns = {}
+    exec("from modules.features.extract import *", ns)                    # noqa: S102
+    bands = oracle.stage1_preprocess(scene["dn"])
+    b, g, r, n, s = [oracle.robust_normalize(x) for x in bands[:5]]
+    features = dict(ndvi=oracle.calculate_ndvi(n, r), ndwi=oracle.calculate_ndwi(g, n), mndwi=oracle.calculate_mndwi(g, s),
+                    ndbi=oracle.calculate_ndbi(s, n), height=600, width=600)
+    img_shape = (600, 600)
+    px = img_shape[0] * img_shape[1]
+    np_ = ns["np"]
+    veg = ns["extract_vegetation_by_threshold"](features, ndvi_threshold=0.25, min_area=int(px * 0.0005))
+    water = ns["extract_water_by_threshold"](features, ndwi_threshold=0.05, min_area=int(px * 0.0002))
+    built = ns["extract_builtup_by_threshold"](features, ndbi_threshold=0.0, ndvi_threshold_for_builtup=0.2, min_area=int(px * 0.001))
+    final = np_.zeros(img_shape, dtype=np_.uint8)
+    for mask, cid in ((built, 3), (veg, 1), (water, 2)):
+        assert mask.shape == img_shape and mask.dtype == np.uint8
+        final[mask == 1] = cid
+    bare = ns["extract_bareland_by_rule"](features, vegetation_mask=(final == 1), water_mask=(final == 2), builtup_mask=(final == 3),
+                                          min_area=int(px * 0.0005))
+    assert bare.shape == img_shape and bare.any()
+    final[(bare == 1) & (final == 0)] = 4
+    want = oracle.rule_based_classification(features)
+    assert np.array_equal(final, want)
+    assert np.array_equal(ns["rule_based_classification"](features), want)
+    assert set(np.unique(final)) == {0, 1, 2, 3, 4} or set(np.unique(final)) >= {0, 1, 4}
+
+
+def test_otsu_hole_fill_and_large_ellipses_vs_oracle(ctx, scene, oracle):
+    """threshold_segmentation(otsu=True) (extract.py:358-371), advanced_post_processing with even / zero kernel sizes
+    (binary_fill_holes, :314-316) and elliptical elements beyond 5 x 5: bit for bit against the oracle (scipy for the
+    hole fill), float32 and float64 planes, NaN pixels, planes without contrast."""
+    from modules.features import extract as E
+    from rsseg import _lib as L
+    from scipy import ndimage
+    rng = np.random.default_rng(21)
+    bands = oracle.stage1_preprocess(scene["dn"])
+    b, g, r, n, s = [oracle.robust_normalize(x) for x in bands[:5]]
+    ndvi = oracle.calculate_ndvi(n, r)
+    planes = [ndvi, ndvi.astype(np.float64) * 1.000001, rng.normal(0, 1, (257, 131)).astype(np.float32),
+              np.where(rng.random((90, 70)) < 0.5, rng.normal(3, 0.2, (90, 70)), rng.normal(9, 0.5, (90, 70))),
+              (rng.random((50, 50)) * 1e-12).astype(np.float32), rng.integers(0, 7, (40, 40)).astype(np.float32)]
+    withnan = ndvi.copy()
+    withnan[::7, ::5] = np.nan
+    planes.append(withnan)
+    for i, a in enumerate(planes):
+        for above in (True, False):
+            want = oracle.threshold_segmentation(a, None, above=above, otsu=True)
+            got = E.threshold_segmentation(a, 123.0, above=above, otsu=True)
+            assert got.dtype == np.uint8 and np.array_equal(got, want), (i, above, int((got != want).sum()))
+    d = ctx.to_device(np.ascontiguousarray(ndvi).reshape(-1))
+    _, level, mn, mx = ctx.otsu_mask(d)
+    stretched = np.clip((ndvi - ndvi.min()) / (ndvi.max() - ndvi.min() + 1e-10) * 255, 0, 255).astype(np.uint8)
+    assert level == oracle.otsu_level_u8(stretched) and mn == float(ndvi.min()) and mx == float(ndvi.max())
+    for a in (np.full((9, 11), 0.25, np.float32), np.full((3, 3), np.nan, np.float32), np.zeros((4, 4))):
+        assert not E.threshold_segmentation(a, 0, otsu=True).any() and E.threshold_segmentation(a, 0, above=False, otsu=True).all()
+    # float64 planes compare in float64 (a value one ulp above a threshold that float32 would round onto it)
+    t = 0.2
+    x64 = np.array([[t, np.nextafter(t, 1), np.nextafter(t, 0), np.nan]])
+    assert E.threshold_segmentation(x64, t).tolist() == (np.nan_to_num(x64) > t).astype(np.uint8).tolist() == [[0, 1, 0, 0]]
+    assert E.threshold_segmentation(x64, t, above=False).tolist() == [[0, 0, 1, 1]]
+    # hole fill
+    for H, W, p in ((64, 64, 0.55), (97, 131, 0.7), (33, 200, 0.62), (1, 9, 0.5), (7, 1, 0.5), (2, 2, 0.5)):
+        m = (rng.random((H, W)) < p).astype(np.uint8)
+        got = ctx.fill_holes(ctx.to_device(m.reshape(-1)), H, W).cpu().numpy().reshape(H, W)
+        assert np.array_equal(got, ndimage.binary_fill_holes(m).astype(np.uint8)), (H, W)
+    ring = np.zeros((300, 300), np.uint8)
+    yy, xx = np.mgrid[:300, :300]
+    rr = np.hypot(yy - 150, xx - 150)
+    ring[(rr < 140) & (rr > 100)] = 1
+    ring[(rr < 60) & (rr > 30)] = 1
+    ring[150, 0:60] = 0                        # a cut through the outer ring: what lies between the rings is no longer a hole
+    got = ctx.fill_holes(ctx.to_device(ring.reshape(-1)), 300, 300).cpu().numpy().reshape(300, 300)
+    assert np.array_equal(got, ndimage.binary_fill_holes(ring).astype(np.uint8)) and got[150, 150] == 1
+    m = (rng.random((120, 140)) < 0.6).astype(np.uint8)
+    for k in (0, 2, 4, 6):
+        for fill in (True, False):
+            for min_area in (0, 12):
+                want = oracle.advanced_post_processing(m, min_area, k, fill)
+                got = E.advanced_post_processing(m, min_area, k, fill)
+                assert np.array_equal(got, want), (k, fill, min_area)
+    # elliptical elements beyond 5 x 5
+    d = ctx.to_device(m.reshape(-1))
+    for k in (7, 9, 15, 31):
+        for name, op in (("erosion", L.MORPH_ERODE), ("dilation", L.MORPH_DILATE), ("opening", L.MORPH_OPEN), ("closing", L.MORPH_CLOSE)):
+            assert np.array_equal(ctx.morph_ellipse(d, 120, 140, k, op).cpu().numpy().reshape(120, 140), oracle.morph_ellipse(m, k, name)), (k, name)
+    assert np.array_equal(E.advanced_post_processing(m, 30, 7), oracle.advanced_post_processing(m, 30, 7))
+    assert np.array_equal(E.advanced_post_processing(m, 30, 1), oracle.advanced_post_processing(m, 30, 1))
+    with pytest.raises(Exception):
+        ctx.morph_ellipse(d, 120, 140, 33, L.MORPH_ERODE)
 
 
 def test_lbp_entropy_gaussian_members_vs_oracle(ctx, crop, oracle):

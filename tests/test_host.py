@@ -273,7 +273,9 @@ def test_run_classification_stage_has_the_reference_signature():
     pos = [p for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
     assert [(p.name, p.default) for p in pos] == [("feature_file_path", inspect.Parameter.empty), ("method", "rule_based"),
                                                   ("output_dir", "segmentation_outputs"), ("use_hierarchical_all", True)]
-    assert {n for n, p in sig.parameters.items() if p.kind == p.KEYWORD_ONLY} == {"n_clusters", "classifier", "feature_keys", "ctx"}
+    assert {n for n, p in sig.parameters.items() if p.kind == p.KEYWORD_ONLY} == {"n_clusters", "classifier", "feature_keys", "ctx",
+                                                                                       "labeled_roi_file", "strict_reference"}
+    assert sig.parameters["labeled_roi_file"].default == "labeled_roi.tif"      # scripts/3:403
     assert sig.parameters["n_clusters"].default == 7          # scripts/3:390
     sig2 = inspect.signature(stages.run_feature_extraction_stage)
     assert list(sig2.parameters)[:3] == ["bands_data", "preprocessing", "texture_band_index"]
@@ -332,3 +334,90 @@ def test_bench_reports_a_failed_rank():
         pytest.skip("needs a host without a GPU")
     r = _bench("--gpus", "2", "--steps", "1", "--no-cpu-baseline")
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+# ---- the star-import surface: `from modules.features.indices import *` (scripts/2:20) and
+# `from modules.features.extract import *` (scripts/3:25) are how the reference's scripts reach the path ----
+OUT_OF_SCOPE_LIBRARY_NAMES = {"plt", "cv2"}     # matplotlib / OpenCV modules the reference leaks through import *: not re-exported
+PLOT_NAMES = {"visualize_hierarchical_features", "create_classification_map", "visualize_combined_indices"}   # resolve, draw nothing
+
+
+@pytest.mark.parametrize("script, mirror", [("scripts/2_feature_extraction.py", "modules.features.indices"),
+                                            ("scripts/3_classification.py", "modules.features.extract")])
+def test_star_import_resolves_every_name_the_reference_scripts_use(golden_dir, script, mirror):
+    """tests/golden/star_import_names.json (oracle/gen_names.py: ast over the reference, identifiers only) lists what each
+    script resolves through its star-import and what it imports by name.  Every one of them must come out of
+    `from <mirror> import *`, except the two library modules above; the plot names resolve to functions that draw nothing."""
+    import json
+    spec = json.load(open(os.path.join(golden_dir, "star_import_names.json")))[script]
+    assert spec["star_import_of"] == mirror and not spec["free_names_the_module_does_not_define"]
+    ns = {}
+    exec(f"from {mirror} import *", ns)                                   # noqa: S102 — what the scripts do
+    wanted = set(spec["resolved_through_star_import"]) | set(spec["imported_by_name"])
+    assert len(wanted) >= 15
+    missing = sorted(n for n in wanted - OUT_OF_SCOPE_LIBRARY_NAMES if n not in ns)
+    assert not missing, f"`from {mirror} import *` does not provide {missing}"
+    for n in wanted & OUT_OF_SCOPE_LIBRARY_NAMES:
+        assert spec["resolved_through_star_import"][n]["kind"] == "import"   # a library module, not a function of the path
+    mod = __import__(mirror, fromlist=["*"])
+    for n in sorted(wanted - OUT_OF_SCOPE_LIBRARY_NAMES):
+        if spec["resolved_through_star_import"].get(n, {}).get("kind") == "function" or n in spec["imported_by_name"]:
+            assert callable(ns[n]) and ns[n].__module__ == mirror, n
+    assert set(mod.PLOTTING_NAMES) == {n for n in mod.__all__ if n in PLOT_NAMES | {"visualize_selected_features"}}
+    assert (wanted & PLOT_NAMES) <= set(mod.PLOTTING_NAMES)
+
+
+def test_mirror_signatures_equal_the_reference_for_every_mirrored_function(golden_dir):
+    """Positional order and defaults of every function both modules define, against the signature strings the fixture
+    holds (names and default literals only)."""
+    import inspect
+    import json
+    spec = json.load(open(os.path.join(golden_dir, "star_import_names.json")))
+    checked = 0
+    for mirror in ("modules.features.indices", "modules.features.extract"):
+        mod = __import__(mirror, fromlist=["*"])
+        for name, want in spec[mirror]["signatures"].items():
+            fn = getattr(mod, name, None)
+            if fn is None:
+                continue          # a reference function the stages never call (Gabor, fusion helpers, ...): not mirrored
+            got = [[p.name, None if p.default is inspect.Parameter.empty else repr(p.default)] for p in inspect.signature(fn).parameters.values()]
+            norm = lambda sig: [[a, None if d is None else d.replace(" ", "").replace("math.pi", "np.pi")] for a, d in sig]   # noqa: E731
+            g, w = norm(got), norm(want)
+            for (ga, gd), (wa, wd) in zip(g, w):
+                assert ga == wa, f"{mirror}.{name}: parameter {ga!r} != {wa!r}"
+                if wd is not None and "np.pi" not in wd:
+                    assert gd is not None and eval(gd) == eval(wd), f"{mirror}.{name}({wa}): default {gd} != {wd}"   # noqa: S307
+            assert len(g) == len(w), f"{mirror}.{name}: {len(g)} parameters, the reference has {len(w)}"
+            checked += 1
+    assert checked >= 30
+
+
+def test_save_classification_as_geotiff_follows_the_reference(tmp_path, capsys):
+    """extract.py:778-833: empty result / incomplete metadata / shape mismatch -> message and no file; dtype by value range;
+    nodata 0; LZW tiles; the file is read back by libtiff (Pillow)."""
+    from modules.features.extract import save_classification_as_geotiff
+    from rsseg.tiff import read_tiff, read_tiff_georef
+    meta = {"transform": (30.0, 0.0, 500000.0, 0.0, -30.0, 4100000.0), "crs": "EPSG:32650", "width": 300, "height": 260}
+    p = str(tmp_path / "c.tif")
+    assert save_classification_as_geotiff(np.zeros((0, 0)), meta, p) is None and not os.path.exists(p)
+    assert "分类结果为空" in capsys.readouterr().out
+    assert save_classification_as_geotiff(np.ones((260, 300), np.uint8), {k: v for k, v in meta.items() if k != "crs"}, p) is None
+    assert "元数据不完整" in capsys.readouterr().out and not os.path.exists(p)
+    assert save_classification_as_geotiff(np.ones((10, 10), np.uint8), meta, p) is None and not os.path.exists(p)
+    assert "does not match" in capsys.readouterr().out
+    rng = np.random.default_rng(5)
+    for hi, dt, src in ((7, np.uint8, np.int32), (300, np.uint16, np.int64), (70000, np.int32, np.int64), (5, np.uint8, np.float64)):
+        a = rng.integers(0, hi + 1, (260, 300)).astype(src)
+        a[0, 0] = hi
+        save_classification_as_geotiff(a, meta, p)
+        assert "已保存" in capsys.readouterr().out
+        back = read_tiff(p)
+        assert back.dtype == dt and back.shape == (1, 260, 300) and np.array_equal(back[0], a.astype(dt))
+        g = read_tiff_georef(p)
+        assert g["nodata"] == 0 and g["epsg"] == 32650 and g["transform"] == meta["transform"]
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(p)), a.astype(dt))
+        os.remove(p)
+    neg = np.full((260, 300), -3, np.int64)
+    save_classification_as_geotiff(neg, meta, p)
+    assert read_tiff(p).dtype == np.int32

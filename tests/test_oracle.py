@@ -284,6 +284,55 @@ def test_cv2_skimage_restatements_known_answers(oracle):
     assert oracle.disk(1).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]] and int(oracle.disk(3).sum()) == 29 and int(oracle.disk(5).sum()) == 81
 
 
+def test_otsu_fill_holes_and_ellipse_restatements_known_answers(oracle):
+    """threshold_segmentation(otsu=True) and the even-kernel branch of advanced_post_processing (extract.py:358-371, 314-316).
+    cv2 is absent: the Otsu level is pinned to (a) the textbook definition evaluated independently — the level maximising the
+    between-class variance w0 * w1 * (mu0 - mu1)^2, the FIRST such level as OpenCV scans upwards — and (b) the known answer for a
+    two-valued image (every level between the two values separates the same classes, so the lower value is returned).
+    binary_fill_holes is scipy itself; the elliptical element is pinned to the two matrices cv2's documentation shows for
+    MORPH_ELLIPSE (3 x 3: the cross; 5 x 5: the square without its corner pairs) and to its symmetry at 7 / 9 / 11."""
+    rng = np.random.default_rng(3)
+    two = np.where(rng.random((40, 50)) < 0.3, 200, 10).astype(np.uint8)
+    assert oracle.otsu_level_u8(two) == 10
+    for trial in range(6):
+        a = np.clip(np.where(rng.random((64, 64)) < 0.4, rng.normal(60, 12, (64, 64)), rng.normal(170, 25, (64, 64))), 0, 255).astype(np.uint8)
+        h = np.bincount(a.ravel(), minlength=256).astype(np.float64) / a.size
+        lv = np.arange(256.0)
+        w0 = np.cumsum(h)
+        m0 = np.cumsum(h * lv)
+        w1 = 1 - w0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sig = np.where((w0 > 1e-6) & (w1 > 1e-6), w0 * w1 * (m0 / w0 - (m0[-1] - m0) / w1) ** 2, 0)
+        best = int(np.argmax(sig))
+        got = oracle.otsu_level_u8(a)
+        assert sig[got] >= sig[best] * (1 - 1e-12) and abs(got - best) <= 1, (trial, got, best)
+        assert 75 < got < 150                                            # between the two modes
+    img = rng.normal(0.2, 0.05, (30, 30)).astype(np.float32)
+    img[:, 15:] += 0.5
+    m = oracle.threshold_segmentation(img, None, otsu=True)
+    assert m.dtype == np.uint8 and m[:, :15].sum() == 0 and m[:, 15:].all()
+    assert np.array_equal(oracle.threshold_segmentation(img, None, above=False, otsu=True), 1 - m)
+    flat = np.full((5, 5), 0.3, np.float32)
+    assert not oracle.threshold_segmentation(flat, None, otsu=True).any() and oracle.threshold_segmentation(flat, None, above=False, otsu=True).all()
+    assert oracle.ellipse_element(3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert oracle.ellipse_element(5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    for k in (7, 9, 11):
+        se = oracle.ellipse_element(k)
+        assert np.array_equal(se, se[::-1]) and np.array_equal(se, se[:, ::-1]) and se[k // 2].all() and se[0].sum() == 1
+    ring = np.zeros((20, 20), np.uint8)
+    ring[5:15, 5:15] = 1
+    ring[8:12, 8:12] = 0                    # a hole
+    ring[0:3, 0:3] = 1
+    ring[1, 1] = 0                          # a one-pixel hole in a block touching the border
+    ring[17:20, 10:13] = 1
+    ring[19, 11] = 0                        # a notch open to the border: not a hole
+    out = oracle.advanced_post_processing(ring, min_area=0, smooth_kernel_size=4)
+    assert out[8:12, 8:12].all() and out[1, 1] == 1 and out[19, 11] == 0
+    assert np.array_equal(oracle.advanced_post_processing(ring, min_area=0, smooth_kernel_size=0), out)
+    assert np.array_equal(oracle.advanced_post_processing(ring, min_area=0, smooth_kernel_size=4, fill_holes=False), ring)
+    assert oracle.advanced_post_processing(ring, min_area=10, smooth_kernel_size=2).sum() == 100      # the two small blocks go
+
+
 def test_pin_report_is_committed(golden_dir):
     rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))
     assert rep["class_map_agreement"] >= 0.999
