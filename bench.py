@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and GLCM-step-7 side measurements")
+    ap.add_argument("--no-c5-extra", action="store_true", help="c3 at 16384: skip the config-5 side measurement (forest fit on the host + two forest steps)")
     ap.add_argument("--weak", action="store_true", help="N > 1: H rows per rank ((N*H) x W scene) instead of one H x W raster split N ways")
     ap.add_argument("--overlap", action="store_true", help="c3, N = 1: GLCM chain on a second HIP stream (profiles/r01_overlap_note.md)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -454,7 +455,14 @@ def main():
         if cfg == "c3" and H == 16384:
             extras["north_star_c2_16384"] = dict(timed(lambda: run_c2(ctx, P, bands, 6, n_global)),
                                                  note="BASELINE.json north_star's literal target configuration: 7 spectral indices + KMeans(k=6) on the 16384x16384x7 raster, 1 GPU (target: >= 100 Mpixel/s)")
-        extras["pcie_inclusive"] = pcie_inclusive(torch, device, ctx, bands, step, n_global)
+        if cfg == "c3" and H == 16384 and not args.no_c5_extra:
+            extras["c5_16384"] = c5_extra(torch, dist, device, ctx, P, bands, H, W, n_global)
+        step_qb = None
+        if cfg == "c3":
+            def step_qb(dev_bands, qb):
+                lab, m, _ = P.config3(ctx, dev_bands, H, W, k, 7, args.glcm_step, 3, n_global, qb=qb)
+                return lab, m
+        extras["pcie_inclusive"] = pcie_inclusive(torch, device, ctx, bands, step, n_global, step_qb)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -615,64 +623,183 @@ def forest_visits_per_px(torch, P, ctx, bands, H, W, n_global, model, sample=655
         return None
 
 
-def pcie_inclusive(torch, device, ctx, bands, step, n_global):
-    """The second figure SURVEY.md §8d asks for, each as ONE measured pass (wall clock around upload -> step -> download,
-    transfers not overlapped with compute): (a) the 7 bands as float32 from pinned host memory, int32 / int64 labels back;
-    (b) the bands as the 8-bit digital numbers they are (the TM tiles the reference reads are uint8) through
-    Context.upload_band — one byte per pixel over PCIe, one byte per pixel in HBM (the kernels read 8-bit planes) — and uint8 class ids back.
-    Never the bench `value`."""
+def c5_extra(torch, dist, device, ctx, P, bands, H, W, n_global):
+    """BASELINE configs[4] on one GPU as a side figure of the default line: the 19-feature stack + RandomForest(100 trees,
+    max_depth 16) inference on the same 16384^2 raster.  The forest is fitted on the host OUTSIDE the timed region (as in
+    `--config c5`); two timed steps."""
     try:
-        host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in bands]
-        for h, b in zip(host, bands):
-            h.copy_(b)
+        t_fit = time.perf_counter()
+        fm = fit_c5_forest(torch, dist, device, P, 0, 1, W)
+        t_fit = time.perf_counter() - t_fit
+        ctx.forest_load(fm["flat"])
+
+        def st():
+            planes, _ = P.feature_stack19(ctx, bands, H, W, n_global=n_global)
+            return ctx.forest_predict(P.stack19_forest_planes(ctx, planes))
+
+        lab = st()
+        del lab
         torch.cuda.synchronize()
-        step()                                  # warm
-        torch.cuda.synchronize()
-        dev = [torch.empty_like(b) for b in bands]
-        lab0, _ = step()
-        lab_host = torch.empty(lab0.numel(), dtype=lab0.dtype, pin_memory=True)   # the caller's result buffer, allocated once
-        del lab0
-        torch.cuda.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.host_syncs(reset=True)
+        reps = 2
         t0 = time.perf_counter()
-        for h, d in zip(host, dev):
-            d.copy_(h, non_blocking=True)
+        for _ in range(reps):
+            lab = st()
+            del lab
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        labels, _ = step(bands=dev)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        lab_host.copy_(labels, non_blocking=True)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        gb = sum(b.numel() * 4 for b in bands) / 1e9
-        out = {"value": round(n_global / 1e6 / (t3 - t0), 2), "unit": "Mpixel/s", "pass_ms": round((t3 - t0) * 1e3, 1),
-               "h2d_ms": round((t1 - t0) * 1e3, 1), "h2d_GBs": round(gb / (t1 - t0), 1), "compute_ms": round((t2 - t1) * 1e3, 1),
-               "d2h_labels_ms": round((t3 - t2) * 1e3, 1),
-               "note": "one pass: 7 float32 bands pinned host -> HBM, one step, labels -> pinned host"}
-        del host, dev, lab_host, labels
-        host8 = [torch.empty(b.numel(), dtype=torch.uint8, pin_memory=True) for b in bands]
-        for h, b in zip(host8, bands):
-            h.copy_(b.to(torch.uint8))
-        lab_host8 = torch.empty(bands[0].numel(), dtype=torch.uint8, pin_memory=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dev8 = [ctx.upload_band(h.numpy()) for h in host8]         # uint8 over PCIe, uint8 in HBM: no widening pass
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        labels, _ = step(bands=dev8)
-        lab8 = labels.to(torch.uint8)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        lab_host8.copy_(lab8, non_blocking=True)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        out["uint8_bands"] = {"value": round(n_global / 1e6 / (t3 - t0), 2), "pass_ms": round((t3 - t0) * 1e3, 1),
-                              "h2d_ms": round((t1 - t0) * 1e3, 1), "compute_ms": round((t2 - t1) * 1e3, 1),
-                              "d2h_uint8_labels_ms": round((t3 - t2) * 1e3, 1),
-                              "note": "one pass: 7 uint8 bands pinned host -> HBM (they stay uint8: the kernels read 8-bit planes), one step, uint8 class ids -> pinned host"}
+        t = (time.perf_counter() - t0) / reps
+        fms, fcnt = ctx.prof_get("forest")
+        syncs = ctx.host_syncs()
+        ctx.prof_enable(False)
+        visits = forest_visits_per_px(torch, P, ctx, bands, H, W, n_global, fm["model"])
+        out = {"ms_per_step": round(t * 1e3, 2), "value": round(n_global / 1e6 / t, 2), "forest_ms": round(fms / max(fcnt, 1), 2),
+               "host_syncs_per_step": round(syncs / reps, 1), "forest_fit_s_outside_timing": round(t_fit, 1),
+               "note": "BASELINE configs[4] on one GPU: 19-feature stack (indices, PCA, 7x7 context, GLCM 21/21, gradient, local std, Sobel) + "
+                       "RandomForest(100 trees, max_depth 16) inference, int64 labels; same raster"}
+        if visits:
+            per_s = n_global * visits / (fms / max(fcnt, 1) / 1e3)
+            out["forest"] = {"bound": "lds_gather", "node_visits_per_px": round(visits, 1), "node_visits_per_s": round(per_s, 0),
+                             "peak_node_visits_per_s": round(FOREST_VISITS_PEAK, 0), "frac": round(per_s / FOREST_VISITS_PEAK, 4)}
         return out
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+def pcie_inclusive(torch, device, ctx, bands, step, n_global, step_qb=None):
+    """The second figure SURVEY.md §8d asks for: the bands start in pinned HOST memory and the label map ends there.
+    Never the bench `value`.  Four measurements, each for float32 bands (int32 / int64 labels back) and for the 8-bit
+    digital numbers the TM tiles are (Context.upload_band: one byte per pixel over PCIe and in HBM, uint8 class ids back):
+      serial            upload -> step -> download, nothing overlapped.  The device planes are touched and one untimed step
+                        runs on them first, so `compute_ms` is the step itself (r03 had allocator growth / first touch inside)
+      pipelined         one pass, one raster: the bands cross PCIe one after the other on a copy stream and each band's
+                        order statistics (K1) are taken as soon as it has landed, while the next band is still in flight;
+                        the rest of the step needs every band's percentiles and starts when the last select is done.
+                        (Per-band, not per 2048-row stripe: a select is per band; K1 is ~0.2 ms per band of a 19 ms upload.)
+      double_buffered   a stream of rasters, what a caller with many tiles does: raster i+1 is uploaded and the labels of
+                        raster i-1 are downloaded (separate copy streams, PCIe is full duplex) while raster i is computed;
+                        steady-state time per raster over three rasters."""
+    try:
+        out = {}
+        for kind in ("float32_bands", "uint8_bands"):
+            u8 = kind == "uint8_bands"
+            src = [b.to(torch.uint8) for b in bands] if u8 else bands
+            host = [torch.empty(b.numel(), dtype=b.dtype, pin_memory=True) for b in src]
+            for h, b in zip(host, src):
+                h.copy_(b)
+            del src
+            sets = [[torch.empty(h.numel(), dtype=h.dtype, device=device) for h in host] for _ in range(2)]
+            for st in sets:                          # touch the fresh planes, then one untimed step on each set
+                for d, h in zip(st, host):
+                    d.copy_(h, non_blocking=True)
+                lab0, _ = step(bands=st)
+            fin = (lambda t: t.to(torch.uint8)) if u8 else (lambda t: t)
+            lab0 = fin(lab0)
+            lab_host = [torch.empty(lab0.numel(), dtype=lab0.dtype, pin_memory=True) for _ in range(2)]
+            del lab0
+            torch.cuda.synchronize()
+            dev = sets[0]
+            res = {}
+            # ---- serial ----
+            t0 = time.perf_counter()
+            for h, d in zip(host, dev):
+                d.copy_(h, non_blocking=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            labels, _ = step(bands=dev)
+            labels = fin(labels)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            lab_host[0].copy_(labels, non_blocking=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            gb = sum(h.numel() * h.element_size() for h in host) / 1e9
+            res["serial"] = {"value": round(n_global / 1e6 / (t3 - t0), 2), "pass_ms": round((t3 - t0) * 1e3, 1), "h2d_ms": round((t1 - t0) * 1e3, 1),
+                             "h2d_GBs": round(gb / (t1 - t0), 1), "compute_ms": round((t2 - t1) * 1e3, 1), "d2h_labels_ms": round((t3 - t2) * 1e3, 1)}
+            del labels
+            main = torch.cuda.current_stream()
+            up, down = torch.cuda.Stream(), torch.cuda.Stream()
+            # ---- pipelined single pass (config 3 only: needs the per-band select entry) ----
+            if step_qb is not None:
+                from rsseg import pipeline as P
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                evs = []
+                with torch.cuda.stream(up):
+                    for h, d in zip(host, dev):
+                        d.copy_(h, non_blocking=True)
+                        e = torch.cuda.Event()
+                        e.record(up)
+                        evs.append(e)
+                qb = []
+                for d, e in zip(dev, evs):
+                    main.wait_event(e)
+                    qb.append(P.band_quantile_bundle(ctx, d, n_global))    # waits for this band only; the later bands keep flowing
+                t1 = time.perf_counter()
+                labels, _ = step_qb(dev, qb)
+                labels = fin(labels)
+                lab_host[0].copy_(labels, non_blocking=True)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                res["pipelined"] = {"value": round(n_global / 1e6 / (t3 - t0), 2), "pass_ms": round((t3 - t0) * 1e3, 1),
+                                    "upload_and_selects_ms": round((t1 - t0) * 1e3, 1), "rest_of_step_and_download_ms": round((t3 - t1) * 1e3, 1)}
+                del labels
+            # ---- double-buffered stream of rasters ----
+            torch.cuda.synchronize()
+            n_r = 4
+            done_up = [None] * (n_r + 1)
+            done_cmp = [None] * (n_r + 1)
+            with torch.cuda.stream(up):
+                for h, d in zip(host, sets[0]):
+                    d.copy_(h, non_blocking=True)
+                done_up[0] = torch.cuda.Event()
+                done_up[0].record(up)
+            marks = []
+            keep = []
+            for i in range(n_r):
+                cur, nxt = sets[i & 1], sets[(i + 1) & 1]
+                if i + 1 < n_r:
+                    with torch.cuda.stream(up):                   # raster i+1 goes up while raster i is computed
+                        if done_cmp[i - 1] is not None:
+                            up.wait_event(done_cmp[i - 1])        # its buffers were read by raster i-1's step
+                        for h, d in zip(host, nxt):
+                            d.copy_(h, non_blocking=True)
+                        done_up[i + 1] = torch.cuda.Event()
+                        done_up[i + 1].record(up)
+                main.wait_event(done_up[i])
+                labels, _ = step(bands=cur)
+                labels = fin(labels)
+                done_cmp[i] = torch.cuda.Event()
+                done_cmp[i].record(main)
+                with torch.cuda.stream(down):                     # labels of raster i come down beside raster i+1's compute
+                    down.wait_event(done_cmp[i])
+                    lab_host[i & 1].copy_(labels, non_blocking=True)
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(down)
+                    marks.append(e)
+                keep.append(labels)                               # alive until its download has run
+                if len(keep) > 2:
+                    marks[len(keep) - 3].synchronize()
+                    keep[len(keep) - 3] = None
+            torch.cuda.synchronize()
+            per = marks[0].elapsed_time(marks[-1]) / (n_r - 1)
+            res["double_buffered"] = {"value": round(n_global / 1e6 / (per * 1e-3), 2), "ms_per_raster": round(per, 1), "rasters": n_r - 1,
+                                      "bound": "upload" if res["serial"]["h2d_ms"] > res["serial"]["compute_ms"] else "compute"}
+            out[kind] = res
+            del host, sets, lab_host, keep
+            torch.cuda.empty_cache()
+        f = out["float32_bands"]
+        flat = dict(f["serial"], unit="Mpixel/s", note="serial: 7 float32 bands pinned host -> HBM, one step, labels -> pinned host; planes pre-touched, one untimed step first")
+        flat["pipelined"] = f.get("pipelined")
+        flat["double_buffered"] = f["double_buffered"]
+        flat["uint8_bands"] = dict(out["uint8_bands"]["serial"], pipelined=out["uint8_bands"].get("pipelined"),
+                                   double_buffered=out["uint8_bands"]["double_buffered"],
+                                   note="the same with the bands as uint8 (they stay uint8 in HBM: the kernels read 8-bit planes) and uint8 class ids back")
+        return flat
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        return {"error": repr(e), "trace": traceback.format_exc()[-800:]}
 
 
 def run_c2(ctx, P, bands, k, n_global):

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct planes { const float *p[32]; };
@@ -41,6 +42,72 @@ __global__ __launch_bounds__(256) void k_read(planes pl, float *rw, int64_t n, f
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// Write-heavy pattern of the fused index + projection pass (k3_indices_project, config 3): NR float32 planes read (7 raw
+// bands = 28 B/px), NW float32 planes written (7 indices + 3 components = 40 B/px) and one uint8 plane written (1 B/px).
+// MAP 0: grid-stride over 16-byte vectors with a persistent grid (what the kernel does); MAP 1: a workgroup owns a contiguous
+// chunk of 16 tiles x 1024 px (the k-means kernels' mapping).  NT 1: non-temporal stores; NT 2: non-temporal loads too; NT 3: non-temporal loads, plain stores (what the kernel does).
+struct wplanes { float *p[16]; uint8_t *q; };
+template <int NR, int NW, int MAP, int NT>
+__global__ __launch_bounds__(256) void k_rw(planes pl, wplanes wp, int64_t n)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int64_t n4 = n >> 2;
+    auto body = [&](int64_t i) {
+        f4v v[NR];
+#pragma unroll
+        for (int s = 0; s < NR; s++)
+            v[s] = NT >= 2 ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(pl.p[s]) + i) : reinterpret_cast<const f4v *>(pl.p[s])[i];
+        f4v acc = v[0];
+#pragma unroll
+        for (int s = 1; s < NR; s++) acc += v[s];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const f4v o = acc * (float)(w + 1);
+            if (NT == 1 || NT == 2) __builtin_nontemporal_store(o, reinterpret_cast<f4v *>(wp.p[w]) + i);
+            else reinterpret_cast<f4v *>(wp.p[w])[i] = o;
+        }
+        const uint32_t qq = (uint32_t)(int)acc[0] & 0xff;
+        if (NT == 1 || NT == 2) __builtin_nontemporal_store(qq * 0x01010101u, reinterpret_cast<uint32_t *>(wp.q) + i);
+        else reinterpret_cast<uint32_t *>(wp.q)[i] = qq * 0x01010101u;
+    };
+    if (MAP == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) body(i);
+    } else {
+        for (int64_t c = blockIdx.x; c * 4096 < n4; c += gridDim.x)
+            for (int t = 0; t < 16; t++) {
+                const int64_t i = c * 4096 + t * 256 + threadIdx.x;
+                if (i < n4) body(i);
+            }
+    }
+}
+template <int NR, int NW, int MAP, int NT> double run_rw(const float *buf, float *wbuf, unsigned grid, int64_t n, double *ms_out)
+{
+    planes pl;
+    wplanes wp;
+    for (int s = 0; s < 32; s++) pl.p[s] = buf + (int64_t)(s < NR ? s : 0) * n;
+    for (int s = 0; s < 16; s++) wp.p[s] = wbuf + (int64_t)(s < NW ? s : 0) * n;
+    wp.q = (uint8_t *)(wbuf + (int64_t)NW * n);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_rw<NR, NW, MAP, NT>), dim3(grid), dim3(256), 0, 0, pl, wp, n);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f, sum = 0.f;
+    const int reps = 8;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL((k_rw<NR, NW, MAP, NT>), dim3(grid), dim3(256), 0, 0, pl, wp, n);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    *ms_out = sum / reps;
+    const double bytes = (double)n * (4.0 * NR + 4.0 * NW + 1.0);
+    return bytes / (sum / reps * 1e-3) / 1e12;
+}
+
 template <int NS, int RW> double run(const float *buf, float *rw, float *sink, int64_t total_floats)
 {
     const int64_t n = (total_floats / NS) & ~(int64_t)16383;
@@ -62,8 +129,39 @@ template <int NS, int RW> double run(const float *buf, float *rw, float *sink, i
     return bytes / (ms / reps * 1e-3) / 1e12;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "write_heavy")) {
+        // the config-3 raster: 16384 x 16384 px; 7 planes read, 10 float32 + 1 uint8 planes written
+        const int64_t n = (int64_t)16384 * 16384;
+        float *buf, *wbuf;
+        CHECK(hipMalloc(&buf, (size_t)n * 4 * 7));
+        CHECK(hipMalloc(&wbuf, (size_t)n * 4 * 10 + (size_t)n + 4096));
+        CHECK(hipMemset(buf, 0, (size_t)n * 4 * 7));
+        CHECK(hipMemset(wbuf, 0, (size_t)n * 4 * 10 + (size_t)n));
+        double ms;
+        printf("{\n \"note\": \"TB/s (and ms) of the fused index + projection pass's bare access pattern at 16384^2: 7 float32 planes read (28 B/px), 10 float32 + 1 uint8 planes written (41 B/px); 69 B/px = 18.5 GB per launch, average of 8 launches\",\n");
+#define ROW(name, NR, NW, MAP, NT, grid) { const double r = run_rw<NR, NW, MAP, NT>(buf, wbuf, grid, n, &ms); printf(" \"%s\": {\"TBs\": %.3f, \"ms\": %.3f},\n", name, r, ms); }
+        ROW("grid_stride_2048wg", 7, 10, 0, 0, 2048)
+        ROW("grid_stride_1024wg", 7, 10, 0, 0, 1024)
+        ROW("grid_stride_4096wg", 7, 10, 0, 0, 4096)
+        ROW("grid_stride_8192wg", 7, 10, 0, 0, 8192)
+        ROW("grid_stride_one_wg_per_4KiB", 7, 10, 0, 0, 65536 * 4)
+        ROW("grid_stride_2048wg_nt_store", 7, 10, 0, 1, 2048)
+        ROW("grid_stride_2048wg_nt_load_store", 7, 10, 0, 2, 2048)
+        ROW("grid_stride_4096wg_nt_load_store", 7, 10, 0, 2, 4096)
+        ROW("grid_stride_2048wg_nt_load_plain_store", 7, 10, 0, 3, 2048)
+        ROW("grid_stride_8192wg_nt_load_plain_store", 7, 10, 0, 3, 8192)
+        ROW("one_wg_per_4KiB_nt_load_plain_store", 7, 10, 0, 3, 65536 * 4)
+        ROW("chunked_2048wg", 7, 10, 1, 0, 2048)
+        ROW("chunked_16384wg", 7, 10, 1, 0, 16384)
+        ROW("chunked_16384wg_nt_load_store", 7, 10, 1, 2, 16384)
+        ROW("read_7_write_1", 7, 1, 0, 2, 2048)
+        ROW("read_7_write_4", 7, 4, 0, 2, 2048)
+        ROW("read_1_write_10", 1, 10, 0, 2, 2048)
+        { const double r = run_rw<7, 7, 0, 2>(buf, wbuf, 2048, n, &ms); printf(" \"read_7_write_7\": {\"TBs\": %.3f, \"ms\": %.3f}\n}\n", r, ms); }
+        return 0;
+    }
     const int64_t total = (int64_t)15 * 268435456;  // 16 GB of float32, what one Lloyd sweep of config 3 reads
     float *buf, *rw, *sink;
     CHECK(hipMalloc(&buf, total * 4));

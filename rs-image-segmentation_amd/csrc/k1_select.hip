@@ -122,15 +122,20 @@ __global__ __launch_bounds__(THREADS) void k1_hist(const float *__restrict__ x, 
         const int64_t stride = (int64_t)gridDim.x * THREADS;
         int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
         for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {  // UNR 16-byte loads in flight per lane
-            if (PASS == 3) {   // give up as soon as any workgroup met a value that is not a small integer
+            // PASS 3 gives up as soon as any workgroup met a value that is not a small integer.  The flag is requested
+            // TOGETHER with the batch's data (r04; before, the data loads waited for the flag: two dependent memory round
+            // trips per batch) and looked at after the batch — a stale flag costs one more batch, never a result
+            unsigned long long stop = 0;
+            if (PASS == 3) {
                 if (my_bad) __builtin_nontemporal_store(1ull, nan_count + 2);
-                if (__builtin_nontemporal_load(nan_count + 2)) break;
+                stop = __builtin_nontemporal_load(nan_count + 2);
             }
             float4 v[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; u++) v[u] = ld_stream_f4(x, i + u * stride);
 #pragma unroll
             for (int u = 0; u < UNR; u++) { handle(v[u].x); handle(v[u].y); handle(v[u].z); handle(v[u].w); }
+            if (PASS == 3 && stop) { i = n4; break; }   // nothing of this plane's histogram is used any more
         }
         for (; i < n4; i += stride) {
             float4 v = x4[i];
@@ -247,7 +252,11 @@ static int order_stats_core(rsseg_ctx *ctx, const float *const *d_planes, int P,
     }
     attr_lock.unlock();
     const int threads = 1024;
-    const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
+    // 512 workgroups = the two per CU that are resident anyway (66 KB of LDS each): every workgroup clears and flushes its
+    // tables once.  profiles/r04_k1_sweep.json: 0.174 ms per 16384^2 plane (6.2 TB/s) against 0.200 ms with 2048 workgroups
+    int grid_cap = 512;
+    if (const char *e = getenv("RSSEG_K1_GRID")) grid_cap = std::max(1, atoi(e));   // experiments (profiles/r04_k1_sweep.py)
+    const int grid = (int)std::min<int64_t>(grid_cap, std::max<int64_t>(1, ceil_div64(n_local >> 2, threads)));
     auto launch = [&](const float *d_x, int pass, size_t lds, const uint32_t *pre, int npre, unsigned long long *hb, unsigned long long *d_nan) {
 #define SEL_GO(PS, TH) hipLaunchKernelGGL((k1_hist<PS, TH, 4>), dim3(grid), dim3(TH), lds, ctx->stream, d_x, n_local, pre, npre, hb, d_nan)
 #define SEL_PASS(TH)                         \

@@ -811,7 +811,9 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
         RSCHK(mm_begin(ctx, 7 + n_components));
         {
             prof_scope ps(ctx, "indices_project");
-            const dim3 pg((int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
+            int64_t fuse_cap = 2048;
+            if (const char *e = getenv("RSSEG_FUSE_GRID")) fuse_cap = std::max(1, atoi(e));   // experiments (profiles/r04_fuse_sweep.py)
+            const dim3 pg((int)std::min<int64_t>(fuse_cap, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
             switch (nb) {
 #define FUSE_GO(NBV)                                                                                                                   \
     case NBV:                                                                                                                          \

@@ -419,9 +419,16 @@ struct resize_planes {
 // cache lines where two hold its data and the line at each end is fetched again by the neighbouring strip's XCD — 6.8 B/px
 // read for 4 (PMC, r03); a 1 KB segment touches nine for eight.
 #define RS_W 256
+#define RS_AHEAD 8   // source rows requested together: 16 four-byte loads in flight per lane
+// r04: the walk goes over SOURCE rows.  h(y) = src[y][sx] * a0 + src[y][sx1] * a1 is formed once per source row and lane
+// (a destination row's lower row is the next destination row's upper row when the scale is near 1: 2 loads per pixel, not
+// 4), and the taps of the next RS_AHEAD source rows are requested back to back before any of them is used — the r03 form
+// had ONE destination row in flight per wave (four loads, wait, store: a memory round trip per row).  Every destination
+// row py with floor(fy(py)) == y is then written as h(y) * (1 - fy) + h(y + 1) * fy with rows clamped to the image: the
+// operations and operands of resize_px, so the same bits.
 template <bool MM>
 __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int sw, int dh, int dw, double scale_x, double scale_y, int src_row0,
-                                                 int dst_row0, int dh_local, int gx, int R, int plane, uint32_t *__restrict__ mm)
+                                                 int sh_local, int dst_row0, int dh_local, int gx, int R, int plane, uint32_t *__restrict__ mm)
 {
     const float *__restrict__ src = pl.src[plane];
     float *__restrict__ dst = pl.dst[plane];
@@ -438,25 +445,60 @@ __global__ __launch_bounds__(256) void k5_resize(resize_planes pl, int sh, int s
         const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
         const float a0 = 1.0f - fx, a1 = fx;
         const int row_end = min((by + 1) * R, dh_local);
-#pragma unroll 4
-        for (int pyl = by * R; pyl < row_end; pyl++) {
-            const int py = pyl + dst_row0;
-            float fy = (float)(((double)py + 0.5) * scale_y - 0.5);
-            int sy = (int)floorf(fy);
-            fy = fy - (float)sy;
-            const int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
-            const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
-            const float b0 = 1.0f - fy, b1 = fy;
-            const float *r0 = src + (size_t)(y0 - src_row0) * sw, *r1 = src + (size_t)(y1 - src_row0) * sw;
-            const float t00 = r0[sx] * a0, t01 = r0[sx1] * a1, t10 = r1[sx] * a0, t11 = r1[sx1] * a1;
-            const float h0 = t00 + t01, h1 = t10 + t11;
-            const float u0 = h0 * b0, u1 = h1 * b1;
-            const float v = u0 + u1;
-            dst[(size_t)pyl * dw + px] = v;
-            if (MM) {
-                const float z = v != v ? 0.f : v;
-                mn = fminf(mn, z);
-                mx = fmaxf(mx, z);
+        int pyl = by * R;
+        // vertical position of a destination row: floor and fraction, as resize_px computes them
+        auto vpos = [&](int row_local, float &frac) -> int {
+            float fy = (float)(((double)(row_local + dst_row0) + 0.5) * scale_y - 0.5);
+            const int sy = (int)floorf(fy);
+            frac = fy - (float)sy;
+            return sy;
+        };
+        // a source row's address: clamped to the image (the border rule) and to the rows this stripe holds (only rows
+        // requested ahead of need can fall outside; they are never used)
+        const int lo = src_row0, hi = src_row0 + sh_local - 1;
+        auto rowp = [&](int y) -> const float * {
+            y = y < 0 ? 0 : (y > sh - 1 ? sh - 1 : y);
+            y = y < lo ? lo : (y > hi ? hi : y);
+            return src + (size_t)(y - src_row0) * sw;
+        };
+        float fcur;
+        int sy_cur = pyl < row_end ? vpos(pyl, fcur) : 0;
+        int ys = sy_cur;                                   // the source row h_cur belongs to
+        float h_cur;
+        {
+            const float *r = rowp(ys);
+            h_cur = r[sx] * a0 + r[sx1] * a1;
+        }
+        while (pyl < row_end) {
+            float t0[RS_AHEAD], t1[RS_AHEAD];
+#pragma unroll
+            for (int i = 0; i < RS_AHEAD; i++) {
+                const float *r = rowp(ys + 1 + i);
+                t0[i] = r[sx];
+                t1[i] = r[sx1];
+            }
+#pragma unroll
+            for (int i = 0; i < RS_AHEAD; i++) {
+                const float h_next = t0[i] * a0 + t1[i] * a1;
+                while (pyl < row_end && sy_cur == ys + i) {     // wave-uniform: every destination row between the two source rows
+                    const float u0 = h_cur * (1.0f - fcur), u1 = h_next * fcur;
+                    const float v = u0 + u1;
+                    dst[(size_t)pyl * dw + px] = v;
+                    if (MM) {
+                        const float z = v != v ? 0.f : v;
+                        mn = fminf(mn, z);
+                        mx = fmaxf(mx, z);
+                    }
+                    pyl++;
+                    if (pyl < row_end) sy_cur = vpos(pyl, fcur);
+                }
+                h_cur = h_next;
+            }
+            ys += RS_AHEAD;
+            if (pyl < row_end && sy_cur > ys) {             // a gap (downsampling, or a stripe that starts further on): jump
+                ys = sy_cur;
+                const float *r = rowp(ys);
+                h_cur = r[sx] * a0 + r[sx1] * a1;
             }
         }
     }
@@ -718,10 +760,10 @@ static int resize_rows(rsseg_ctx *ctx, const float *const *d_src, int nplanes, i
         const int ny = (int)std::max<int64_t>(1, ceil_div64(dh_local, R));
         const dim3 pg((unsigned)((int64_t)gx * ny));
         if (ctx->mm_collect)
-            hipLaunchKernelGGL(k5_resize<true>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, gx, R, p,
+            hipLaunchKernelGGL(k5_resize<true>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, sh_local, dst_row0, dh_local, gx, R, p,
                                ctx->d_mm);
         else
-            hipLaunchKernelGGL(k5_resize<false>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, dst_row0, dh_local, gx, R, p,
+            hipLaunchKernelGGL(k5_resize<false>, pg, dim3(256), 0, ctx->stream, pl, sh, sw, dh, dw, scale_x, scale_y, src_row0, sh_local, dst_row0, dh_local, gx, R, p,
                                (uint32_t *)nullptr);
     }
     HIPCHK(ctx, hipGetLastError());

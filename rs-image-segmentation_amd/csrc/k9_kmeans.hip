@@ -510,8 +510,10 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
                                                        const scaler_t<T> *__restrict__ sp, const T *__restrict__ cenT,
                                                        const T *__restrict__ csq, uint8_t *__restrict__ labels,
                                                        long long *__restrict__ partial, int64_t nchunks, int ncopies,
-                                                       const int *__restrict__ done)
+                                                       const int *__restrict__ done, int32_t *__restrict__ out32)
 {
+    // out32 (final E-step only, !UPDATE): the caller's int32 label plane is written directly and the uint8 working plane
+    // is neither read nor written (r04; before, a separate kernel widened the uint8 plane afterwards)
     if (done && *done) return;   // a speculatively enqueued iteration behind the one that converged (kl_update)
     constexpr int PXL = vt<T>::PXL;
     constexpr int TILE = KM_THREADS * PXL;
@@ -575,7 +577,15 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
             }
             lab[p] = bl;
         }
-        if (FULL || base + PXL <= n) {
+        if (!UPDATE && out32) {
+            if (FULL || base + PXL <= n) {
+                if constexpr (PXL == 4) *reinterpret_cast<int4 *>(out32 + base) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+                else *reinterpret_cast<int2 *>(out32 + base) = make_int2(lab[0], lab[1]);
+            } else {
+                for (int p = 0; p < PXL; p++)
+                    if (base + p < n) out32[base + p] = lab[p];
+            }
+        } else if (FULL || base + PXL <= n) {
             if constexpr (PXL == 4) {
                 uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
                 my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
@@ -1636,7 +1646,8 @@ i128 limbs(long long hi, long long lo) { return ((i128)hi << 32) + (i128)lo; }
 
 template <typename T, int KMAX, int FR>
 int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done)
+                  const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done,
+                  int32_t *out32)
 {
     if (update) {
         // per device: the dynamic-LDS limit already granted to this instantiation (contexts of several threads may race here)
@@ -1652,21 +1663,23 @@ int launch_lloyd2(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plan
             }
         }
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, true>), dim3((unsigned)nchunks), dim3(KM_THREADS), lds, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies, done);
+                           cenT, csq, labels, partial, nchunks, ncopies, done, (int32_t *)nullptr);
     } else {
         hipLaunchKernelGGL((km_lloyd<T, KMAX, FR, false>), dim3((unsigned)nchunks), dim3(KM_THREADS), 0, ctx->stream, pl, F, k, n, sp,
-                           cenT, csq, labels, partial, nchunks, ncopies, done);
+                           cenT, csq, labels, partial, nchunks, ncopies, done, out32);
     }
     return RSSEG_OK;
 }
 
 template <typename T, int KMAX>
 int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, planes_t pl, int F, int k, int64_t n,
-                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done)
+                 const scaler_t<T> *sp, const T *cenT, const T *csq, uint8_t *labels, long long *partial, int ncopies, const int *done,
+                 int32_t *out32 = nullptr)
 {
-    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
-    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
-    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done);
+    // out32: only the register-resident kernels (F <= 32) write the int32 plane themselves; lloyd_writes_int32() tells the caller
+    if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
+    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
+    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
     // 32 < F <= RSSEG_MAX_FEATURES: the feature-blocked kernel
     if (update) {
         static std::mutex mu;
@@ -2021,7 +2034,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
     // one E-step (+ per-cluster sums when `update`).  from_state: the centres come from the device state (kl_prepare builds
     // their transposed copy and norms; `done`-guarded unless forced); otherwise from the host array C.
-    auto run_lloyd = [&](bool update, bool from_state, bool force) -> int {
+    auto run_lloyd = [&](bool update, bool from_state, bool force, int32_t *out32 = nullptr) -> int {
         if (from_state) {
             // d_cen already holds the transposed centres of the state: kl_prepare before the first iteration, kl_update after each
         } else {
@@ -2047,10 +2060,10 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
                 const size_t l2 = update ? lds : 0;
                 int lrc;
                 switch (KMAX) {
-                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
-                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
-                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
-                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag); break;
+                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
+                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
+                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
+                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
                 }
                 if (lrc != RSSEG_OK) return lrc;
             }
@@ -2269,8 +2282,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             if (end < 0) return end;
         }
     }
-    if (!strict) RSCHK(run_lloyd(false, false, true));
-    if (n > 0) {
+    // the final E-step (labels of the final centres; skipped when the last iteration changed no label) writes the caller's
+    // int32 plane itself when its kernel can (F <= 32, 16-byte aligned plane); otherwise the uint8 plane is widened
+    const bool direct = !strict && F <= 32 && n > 0 && ((uintptr_t)d_labels & 15) == 0;
+    if (!strict) RSCHK(run_lloyd(false, false, true, direct ? d_labels : nullptr));
+    if (n > 0 && !direct) {
         prof_scope ps(ctx, "labels");
         hipLaunchKernelGGL(km_labels_out, dim3((unsigned)std::min<int64_t>(4096, ceil_div64(n, KM_THREADS))), dim3(KM_THREADS), 0, st,
                            d_lab, d_labels, n);

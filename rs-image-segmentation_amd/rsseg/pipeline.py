@@ -251,18 +251,21 @@ def config2(ctx: Context, bands: Sequence, k: int = 6):
 
 @_with_minmax
 def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3,
-            n_global: Optional[int] = None, overlap: bool = False):
+            n_global: Optional[int] = None, overlap: bool = False, qb: Optional[List[dict]] = None):
     """BASELINE config 3: 7 indices + 5 GLCM properties (window 7, 4 angles) + PCA(3) -> 15 float32
     features -> KMeans(k).  One select per band serves all percentile requests (band_quantile_bundle).
     overlap=True enqueues the GLCM chain (quantise -> windows -> 5 bilinear upsamples) on a second HIP
     stream beside the selects / indices / PCA of the other bands and joins before KMeans.  Measured on MI355X
     (profiles/r01_overlap_note.md): the GLCM kernel fills every CU and slows down by what the other stream
-    executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default."""
+    executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default.
+    qb: the bands' quantile bundles when the caller has them already (band_quantile_bundle per band, e.g. computed while the
+    next band was still crossing PCIe); default: one grouped select here."""
     NIR = 3
     if not overlap:
         # one grouped select, then: indices (+ the normalised NIR band only), texture chain on the normalised NIR band
         # re-normalised and quantised in one pass, PCA straight from the RAW bands (normalisation inside its kernels)
-        qb = band_quantile_bundles(ctx, bands, n_global)
+        if qb is None:
+            qb = band_quantile_bundles(ctx, bands, n_global)
         lohi = np.array([[q["lo"], q["hi"]] for q in qb], np.float32)
         fused = all(q["center"] is not None for q in qb)
         want = tuple(i == NIR for i in range(5)) if fused else (True,) * 5
