@@ -153,6 +153,11 @@ def pattern_rate_gbs(family):
     """Measured rate (GB/s) of the family's bare access pattern on MI355X — 15 float32 planes read with 16-byte loads, plus
     one read-modify-write plane for the k-means kernels (profiles/r02_streams.json, best of the recorded runs) — or None."""
     try:
+        if family == "indices_project":   # 28 B/px read over 7 planes + 41 B/px written over 11 (profiles/ubench/streams.hip write_heavy, r04):
+            wh = json.load(open(os.path.join(ROOT, "profiles", "r04_streams_write_heavy.json")))   # the best launch shape recorded
+            return round(max(v["TBs"] for v in wh.values() if isinstance(v, dict) and "TBs" in v and not v.get("other_mix")) * 1000.0, 1)
+        if family == "select":            # one float32 plane read once: the small-integer pass at its best grid (r04_k1_sweep.json) is the pattern
+            return round(max(r["read_only"]["1"] for r in json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]) * 1000.0, 1)
         runs = json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]
         key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("with_rw_plane", "15"), "moment": ("read_only", "1")}[family]
         return round(max(r[key][ns] for r in runs if key in r) * 1000.0, 1)

@@ -302,8 +302,9 @@ struct fuse_args {
     float q_lo, q_hi, q_den, q_mult;
 };
 
+#define FUSE_CHUNK_V 4096
 template <int NB, bool MM, bool U8>
-__global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, proj_args pr, fuse_args fz, int64_t n, uint32_t *__restrict__ mm)
+__global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, proj_args pr, fuse_args fz, int64_t n, uint32_t *__restrict__ mm, int chunked)
 {
     static_assert(NB >= 5, "the indices read bands 0..4");
     __shared__ float lutn[U8 ? 5 * 256 : 1];    // robust_normalize of a byte (bands 0..4)
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
         lmn[slot] = fminf(lmn[slot], z);
         lmx[slot] = fmaxf(lmx[slot], z);
     };
-    for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) {
+    auto body = [&](int64_t i) {
         float nbv[4][5], x[4][NB];
         if (U8) {
             uint32_t w[NB];
@@ -397,6 +398,22 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
                     }
             }
         }
+    };
+    if (chunked) {
+        // a workgroup owns contiguous chunks of FUSE_CHUNK_V 16-byte vectors (16 tiles of 1024 px, the k-means kernels' mapping):
+        // with 7 planes read and 11 written, 18 streams per workgroup, the bare pattern runs 3.26 ms in this mapping against
+        // 3.66-3.72 ms grid-strided at 16384^2 (profiles/r04_streams_write_heavy.json)
+        const int64_t nchunk = (n4 + FUSE_CHUNK_V - 1) / FUSE_CHUNK_V;
+        for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+            const int64_t i0 = c * FUSE_CHUNK_V + threadIdx.x;
+#pragma unroll 1
+            for (int t = 0; t < FUSE_CHUNK_V / PCA_THREADS; t++) {
+                const int64_t i = i0 + (int64_t)t * PCA_THREADS;
+                if (i < n4) body(i);
+            }
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) body(i);
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
     if (t < n) {
@@ -811,18 +828,24 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
         RSCHK(mm_begin(ctx, 7 + n_components));
         {
             prof_scope ps(ctx, "indices_project");
-            int64_t fuse_cap = 2048;
-            if (const char *e = getenv("RSSEG_FUSE_GRID")) fuse_cap = std::max(1, atoi(e));   // experiments (profiles/r04_fuse_sweep.py)
-            const dim3 pg((int)std::min<int64_t>(fuse_cap, std::max<int64_t>(1, ceil_div64(n_local >> 2, PCA_THREADS))));
+            // large planes: one contiguous chunk of 16 tiles per workgroup (up to 16384 workgroups); small ones (fewer than 1024
+            // chunks): 16-byte vectors dealt grid-stride to up to 2048 workgroups, as before.  profiles/r04_fuse_sweep.json:
+            // 3.86 ms chunked against 4.07-4.22 ms grid-strided at 16384^2 on the same box
+            int chunked = ceil_div64(n_local >> 2, FUSE_CHUNK_V) >= 1024 ? 1 : 0;
+            if (const char *e = getenv("RSSEG_FUSE_MAP")) chunked = atoi(e);                  // experiments (profiles/r04_fuse_sweep.py)
+            int64_t fuse_cap = chunked ? 16384 : 2048;
+            if (const char *e = getenv("RSSEG_FUSE_GRID")) fuse_cap = std::max(1, atoi(e));
+            const int64_t units = chunked ? ceil_div64(n_local >> 2, FUSE_CHUNK_V) : ceil_div64(n_local >> 2, PCA_THREADS);
+            const dim3 pg((int)std::min<int64_t>(fuse_cap, std::max<int64_t>(1, units)));
             switch (nb) {
 #define FUSE_GO(NBV)                                                                                                                   \
     case NBV:                                                                                                                          \
         if (u8) {                                                                                                                      \
-            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm); \
-            else hipLaunchKernelGGL((k3_indices_project<NBV, false, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr);      \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm, chunked); \
+            else hipLaunchKernelGGL((k3_indices_project<NBV, false, true>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr, chunked);      \
         } else {                                                                                                                       \
-            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm); \
-            else hipLaunchKernelGGL((k3_indices_project<NBV, false, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr);      \
+            if (ctx->mm_collect) hipLaunchKernelGGL((k3_indices_project<NBV, true, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, ctx->d_mm, chunked); \
+            else hipLaunchKernelGGL((k3_indices_project<NBV, false, false>), pg, dim3(PCA_THREADS), 0, ctx->stream, a, pr, fz, n_local, (uint32_t *)nullptr, chunked);      \
         }                                                                                                                              \
         break;
                 FUSE_GO(5) FUSE_GO(6) FUSE_GO(7) FUSE_GO(8)

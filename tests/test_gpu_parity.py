@@ -822,16 +822,39 @@ def test_config3_pipeline_vs_oracle(ctx, oracle, H, W):
     assert np.array_equal(host(labels), want)
 
 
+def _label_diff_report(got, want, planes64, meta):
+    """How two label maps differ, judged in the product's scaled and centred space: count, the largest squared-distance gap
+    between the two labels' centres at a differing pixel, and how many differing pixels have exactly their two nearest
+    centres as the two labels (a near-tie)."""
+    bad = np.nonzero(got != want)[0]
+    rep = {"differing": int(bad.size)}
+    if bad.size:
+        Xs = planes64[bad] * meta["scale"] + meta["min"] - meta["mean"]
+        C = meta["centers"] - meta["mean"]
+        d = ((Xs[:, None, :] - C[None, :, :]) ** 2).sum(-1)
+        ar = np.arange(bad.size)
+        rep["max_gap"] = float(np.abs(d[ar, got[bad]] - d[ar, want[bad]]).max())
+        order = np.sort(np.argsort(d, axis=1)[:, :2], axis=1)
+        pair = np.sort(np.stack([got[bad], want[bad]], 1), axis=1)
+        rep["near_ties"] = int((order == pair).all(1).sum())
+    return rep
+
+
 @pytest.mark.parametrize("kind", ["easy", "hard"])
 def test_bench_raster_whole_path_vs_cpu_oracle(ctx, oracle, kind):
     """The raster bench.py TIMES (bench.synth_rows: SURVEY 8d's prototypes with the noise drawn on the device; 'hard': the
     continuously mixed form) tied to the oracle at 2048 x 2048: generated on the GPU, copied to the host, pushed through the
-    WHOLE CPU path — oracle feature planes (scikit-learn's own float32 PCA among them) -> oracle KMeans — and compared with
-    the product's config 3: the 12 non-PCA planes bit for bit, the components to the DESIGN 4 bar (within 1e-5 of the
-    float64 evaluation), and the label map against the CPU path's label map.  The count of differing labels is written to
-    gpurun_out/r04/bench_raster_whole_path_<kind>.json and DESIGN 2 quotes it; every differing pixel must be a near-tie
-    between exactly its two labels' centres (as in test_kmeans_full_scene_vs_reference_goldens) when the two runs share
-    their seeds.  (The KMeans kernels alone, on identical planes, are bit-exact: test_config3_pipeline_vs_oracle.)"""
+    WHOLE CPU path — oracle feature planes -> oracle KMeans — and compared with the product's config 3: the 12 non-PCA
+    planes bit for bit, the components within 1e-5 of the float64 evaluation, and three label comparisons
+    (written to gpurun_out/r04/bench_raster_whole_path_<kind>.json; DESIGN 2 quotes them):
+      A  product vs the CPU path with scikit-learn's own float32 PCA (the literal whole path);
+      B  that CPU path vs the same CPU path fed the float64-exact components instead — the REFERENCE's sensitivity to its
+         own ~3e-4 float32 PCA noise;
+      C  product vs the CPU path fed the float64-exact components.
+    C must be the same seeds, the same iteration count and near-ties only.  A is bounded by the recorded count when the
+    seeds agree (easy raster: 4 labels of 4 194 304); when k-means++ draws a different seed in A, the same must happen in
+    B — the reference then disagrees with ITSELF under a perturbation of the size of its own rounding noise, so no
+    implementation can match it label for label — and A is reported, not bounded."""
     import json
     import torch
     import bench
@@ -852,45 +875,41 @@ def test_bench_raster_whole_path_vs_cpu_oracle(ctx, oracle, kind):
         assert np.array_equal(host(planes[i], (H, W)), feats[i]), i
     truth, _ = _pca_truth64(norm)
     pcs, _, _ = oracle.perform_pca(norm, n_components=3)
-    pc_dev_truth, pc_dev_sklearn = [], []
+    dev_truth, dev_sk = [], []
     for i in range(3):
-        got = host(planes[12 + i], (H, W))
-        pc_dev_truth.append(float(np.abs(got - truth[i].reshape(H, W)).max()))
-        pc_dev_sklearn.append(float(np.abs(got - pcs[i]).max()))
-        assert pc_dev_truth[-1] <= 1e-5
-    feats += list(pcs)                                   # the CPU path's own components
-    want, info = oracle.kmeans_fit_planes(feats, 8)
+        gp = host(planes[12 + i], (H, W))
+        dev_truth.append(float(np.abs(gp - truth[i].reshape(H, W)).max()))
+        dev_sk.append(float(np.abs(gp - pcs[i]).max()))
+        assert dev_truth[-1] <= 1e-5
+    cpu_sk, info_sk = oracle.kmeans_fit_planes(feats + list(pcs), 8)                                         # the literal CPU path
+    cpu_ex, info_ex = oracle.kmeans_fit_planes(feats + [truth[i].reshape(H, W).astype(np.float32) for i in range(3)], 8)
     got = host(labels)
-    bad = np.nonzero(got != want)[0]
-    same_seeds = [int(x) for x in meta["init_indices"]] == [int(x) for x in info["init_indices"]]
-    rep = {"raster": f"bench.synth_rows kind={kind}, {H}x{W}", "pixels": H * W, "labels_differing_from_the_cpu_path": int(bad.size),
-           "same_kmeans_seeds": bool(same_seeds), "n_iter_gpu": int(meta["n_iter"]), "n_iter_cpu_path": int(info["n_iter"]),
-           "pc_max_abs_dev_from_float64": pc_dev_truth, "pc_max_abs_dev_from_sklearn_float32": pc_dev_sklearn}
-    if bad.size:
-        X = np.stack([host(p).astype(np.float64) for p in planes], 1)
-        Xs = X * meta["scale"] + meta["min"] - meta["mean"]
-        C = meta["centers"] - meta["mean"]
-        d = ((Xs[bad, None, :] - C[None, :, :]) ** 2).sum(-1)
-        ar = np.arange(bad.size)
-        gap = np.abs(d[ar, got[bad]] - d[ar, want[bad]])
-        rep["max_squared_distance_gap_of_a_differing_pixel"] = float(gap.max())
-        order = np.sort(np.argsort(d, axis=1)[:, :2], axis=1)
-        pair = np.sort(np.stack([got[bad], want[bad]], 1), axis=1)
-        rep["differing_pixels_whose_two_labels_are_their_two_nearest_centres"] = int((order == pair).all(1).sum())
+    X64 = np.stack([host(p).astype(np.float64) for p in planes], 1)
+    seeds = lambda m: [int(x) for x in m["init_indices"]]   # noqa: E731
+    rep = {"raster": f"bench.synth_rows kind={kind}, {H}x{W}", "pixels": H * W,
+           "pc_max_abs_dev_from_float64": dev_truth, "pc_max_abs_dev_from_sklearn_float32": dev_sk,
+           "A_product_vs_cpu_path": dict(_label_diff_report(got, cpu_sk, X64, meta), same_seeds=seeds(meta) == seeds(info_sk),
+                                         n_iter=[int(meta["n_iter"]), int(info_sk["n_iter"])]),
+           "B_cpu_path_vs_cpu_path_with_exact_pca": dict(_label_diff_report(cpu_sk, cpu_ex, X64, meta), same_seeds=seeds(info_sk) == seeds(info_ex),
+                                                         n_iter=[int(info_sk["n_iter"]), int(info_ex["n_iter"])]),
+           "C_product_vs_cpu_path_with_exact_pca": dict(_label_diff_report(got, cpu_ex, X64, meta), same_seeds=seeds(meta) == seeds(info_ex),
+                                                        n_iter=[int(meta["n_iter"]), int(info_ex["n_iter"])])}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04")
     os.makedirs(out, exist_ok=True)
     json.dump(rep, open(os.path.join(out, f"bench_raster_whole_path_{kind}.json"), "w"), indent=1)
     print(json.dumps(rep))
-    assert same_seeds, rep
-    assert bad.size <= BENCH_RASTER_LABEL_BOUND[kind], rep
-    if bad.size:
-        assert rep["max_squared_distance_gap_of_a_differing_pixel"] < 2e-3, rep
-        assert rep["differing_pixels_whose_two_labels_are_their_two_nearest_centres"] == bad.size, rep
+    A, B, Cc = rep["A_product_vs_cpu_path"], rep["B_cpu_path_vs_cpu_path_with_exact_pca"], rep["C_product_vs_cpu_path_with_exact_pca"]
+    assert Cc["same_seeds"] and Cc["n_iter"][0] == Cc["n_iter"][1], rep
+    assert Cc["differing"] <= 64 and Cc.get("near_ties", 0) == Cc["differing"] and Cc.get("max_gap", 0.0) < 2e-3, rep
+    if A["same_seeds"]:
+        assert A["differing"] <= BENCH_RASTER_LABEL_BOUND[kind] and A.get("near_ties", 0) == A["differing"] and A.get("max_gap", 0.0) < 2e-3, rep
+    else:
+        assert not B["same_seeds"], rep     # the reference's own float32 PCA noise moves a seed: it disagrees with itself just the same
 
 
-# labels of the 4 194 304 that may differ between the product and the whole CPU path on the bench rasters at 2048^2: the
-# counts recorded when the test was written (profiles/r04_bench_raster_whole_path_*.json), each pixel proven a near-tie
-BENCH_RASTER_LABEL_BOUND = {"easy": 4194304, "hard": 4194304}
+# labels of the 4 194 304 that may differ between the product and the literal CPU path on the bench rasters at 2048^2 when both
+# draw the same seeds (recorded: easy 4; profiles/r04_bench_raster_whole_path_*.json), each pixel proven a near-tie
+BENCH_RASTER_LABEL_BOUND = {"easy": 16, "hard": 4096}
 
 
 @pytest.mark.parametrize("seed", [20, 22, 25, 26, 29, 30])
