@@ -760,6 +760,306 @@ __global__ __launch_bounds__(256) void k4_glcm_pair(const uint8_t *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k4_glcm_quad (r04) — the dense case with a 2 x 2 BLOCK of windows per thread: A = (x, y), B = (x+1, y), C = (x, y+1),
+// D = (x+1, y+1) on one 8 x 8 patch (16 registers).  The four windows share, per angle, a CORE of pairs (30 of the 42
+// pairs of the 0 / 90 degree angles, 25 of the 36 of 45 / 135), two of them a STRIP of 5 more, and each adds its OWN 7
+// (6): the core is built and sorted once per thread, core + strip merged once per two windows, and a window only sorts
+// its own keys and merges them in — per window 375 compare-exchanges instead of the pair kernel's 446 and 32 packed keys
+// built instead of 46.  The same integer statistics, the same float64 finish (gp_finish): bit-identical.
+//   Packing.  A register carries two angles (low / high half).  For 45 / 135 degrees both halves have the same geometry.
+//   For 0 / 90 degrees the geometry of one is the transpose of the other (0: row strips of 5, column strips of 7;
+//   90: column strips of 5, row strips of 7), so a register "slot" carries the 0-degree keys of one window and the
+//   90-degree keys of its TRANSPOSE partner (A|A, B|C, C|B, D|D): then the merged core + strip array of the top row strip
+//   (0 degrees: A, B) and of the left column strip (90 degrees: A, C) is what slots 0 and 1 both start from, and the
+//   bottom / right one what slots 2 and 3 start from.  The Hq sums of the sets that are split between windows are read
+//   per half from the 32-entry table instead of the table of pair sums.
+// ------------------------------------------------------------------------------------------------
+// two-stage merging network on registers [0, NC + NT + NO): stage 1 merges the sorted runs [0, NC) and [NC, NC + NT)
+// (the logical order afterwards is order1), stage 2 merges that run with the sorted run [NC + NT, NC + NT + NO)
+template <int NC, int NT, int NO> struct quad_net {
+    int a1[(NC + NT) * 8], b1[(NC + NT) * 8], n1;
+    int order1[NC + NT];
+    int a2[(NC + NT + NO) * 8], b2[(NC + NT + NO) * 8], n2;
+    int order2[NC + NT + NO];
+};
+template <int NC, int NT, int NO> constexpr quad_net<NC, NT, NO> make_quad_net()
+{
+    quad_net<NC, NT, NO> s{};
+    int x[NC] = {}, y[NT] = {}, z[NO] = {};
+    for (int i = 0; i < NC; i++) x[i] = i;
+    for (int i = 0; i < NT; i++) y[i] = NC + i;
+    for (int i = 0; i < NO; i++) z[i] = NC + NT + i;
+    int n = 0;
+    oem_build(x, NC, y, NT, s.order1, merge_emit{s.a1, s.b1, &n});
+    s.n1 = n;
+    n = 0;
+    oem_build(s.order1, NC + NT, z, NO, s.order2, merge_emit{s.a2, s.b2, &n});
+    s.n2 = n;
+    return s;
+}
+// zero-one principle, stage by stage (stage 2 starts from any sorted 0 / 1 run laid out in stage 1's order)
+template <int NC, int NT, int NO> constexpr bool quad_net_ok(const quad_net<NC, NT, NO> &s)
+{
+    for (int za = 0; za <= NC; za++)
+        for (int zb = 0; zb <= NT; zb++) {
+            int r[NC + NT] = {};
+            for (int i = 0; i < NC; i++) r[i] = i >= za;
+            for (int i = 0; i < NT; i++) r[NC + i] = i >= zb;
+            for (int c = 0; c < s.n1; c++) {
+                const int lo = r[s.a1[c]] < r[s.b1[c]] ? r[s.a1[c]] : r[s.b1[c]], hi = r[s.a1[c]] + r[s.b1[c]] - lo;
+                r[s.a1[c]] = lo;
+                r[s.b1[c]] = hi;
+            }
+            for (int i = 1; i < NC + NT; i++)
+                if (r[s.order1[i - 1]] > r[s.order1[i]]) return false;
+        }
+    for (int za = 0; za <= NC + NT; za++)
+        for (int zc = 0; zc <= NO; zc++) {
+            int r[NC + NT + NO] = {};
+            for (int i = 0; i < NC + NT; i++) r[s.order1[i]] = i >= za;
+            for (int i = 0; i < NO; i++) r[NC + NT + i] = i >= zc;
+            for (int c = 0; c < s.n2; c++) {
+                const int lo = r[s.a2[c]] < r[s.b2[c]] ? r[s.a2[c]] : r[s.b2[c]], hi = r[s.a2[c]] + r[s.b2[c]] - lo;
+                r[s.a2[c]] = lo;
+                r[s.b2[c]] = hi;
+            }
+            for (int i = 1; i < NC + NT + NO; i++)
+                if (r[s.order2[i - 1]] > r[s.order2[i]]) return false;
+        }
+    return true;
+}
+template <int NC, int NT, int NO> struct quad_holder {
+    static constexpr quad_net<NC, NT, NO> net = make_quad_net<NC, NT, NO>();
+    static_assert(quad_net_ok(net), "two-stage merging network does not merge");
+};
+
+// sets of a group: 0 = core, 1 = strip of slots 0 / 1 (0 degrees: top row; 90: left column; 45 / 135: top row),
+// 2 = strip of slots 2 / 3 (bottom row; right column), 3 + s = own keys of slot s
+template <int G, int SET> __host__ __device__ constexpr int gq_count()
+{
+    return G == 0 ? (SET == 0 ? 30 : (SET <= 2 ? 5 : 7)) : (SET == 0 ? 25 : (SET <= 2 ? 5 : 6));
+}
+template <int G, int SET> __host__ __device__ constexpr gp_pos gq_where(int p, int half)
+{
+    if (G == 0 && half == 0) {   // 0 degrees: (r, c)-(r, c + 1), pair column c in 0..6
+        if (SET == 0) return gp_pos{1 + p / 5, 1 + p % 5, 1 + p / 5, 2 + p % 5, false};
+        if (SET == 1) return gp_pos{0, 1 + p, 0, 2 + p, false};            // top row strip (A, B)
+        if (SET == 2) return gp_pos{7, 1 + p, 7, 2 + p, false};            // bottom row strip (C, D)
+        if (SET == 3) return gp_pos{p, 0, p, 1, false};                    // slot 0: A's left column
+        if (SET == 4) return gp_pos{p, 6, p, 7, false};                    // slot 1: B's right column
+        if (SET == 5) return gp_pos{1 + p, 0, 1 + p, 1, false};            // slot 2: C's left column
+        return gp_pos{1 + p, 6, 1 + p, 7, false};                          // slot 3: D's right column
+    }
+    if (G == 0) {                // 90 degrees: (r, c)-(r + 1, c), pair row r in 0..6
+        if (SET == 0) return gp_pos{1 + p / 6, 1 + p % 6, 2 + p / 6, 1 + p % 6, false};
+        if (SET == 1) return gp_pos{1 + p, 0, 2 + p, 0, false};            // left column strip (A, C)
+        if (SET == 2) return gp_pos{1 + p, 7, 2 + p, 7, false};            // right column strip (B, D)
+        if (SET == 3) return gp_pos{0, p, 1, p, false};                    // slot 0: A's top row
+        if (SET == 4) return gp_pos{6, p, 7, p, false};                    // slot 1: C's bottom row
+        if (SET == 5) return gp_pos{0, 1 + p, 1, 1 + p, false};            // slot 2: B's top row
+        return gp_pos{6, 1 + p, 7, 1 + p, false};                          // slot 3: D's bottom row
+    }
+    // 45 degrees: (r, c)-(r + 1, c + 1); 135 degrees: (r, c + 1)-(r + 1, c); pair row r and pair column c in 0..6
+    const int sh = half == 0 ? 0 : 1;
+    int r = 0, c = 0;
+    if (SET == 0) { r = 1 + p / 5; c = 1 + p % 5; }
+    else if (SET == 1) { r = 0; c = 1 + p; }
+    else if (SET == 2) { r = 6; c = 1 + p; }
+    else if (SET == 3) { r = p; c = 0; }
+    else if (SET == 4) { r = p; c = 6; }
+    else if (SET == 5) { r = 1 + p; c = 0; }
+    else { r = 1 + p; c = 6; }
+    return gp_pos{r, c + sh, r + 1, c + 1 - sh, false};
+}
+
+// builds the packed keys of one set into K[OFF ..).  SPLIT: the Hq table reads are made per half (HqLo / HqHi: the two
+// halves end up in different windows); otherwise one read of the pair-sum table (added to HqLo)
+template <int G, int SET, int OFF, int NK, bool SPLIT>
+__device__ __forceinline__ void gq_build(const unsigned (&P)[8][2], const long long *__restrict__ hq2, const long long *__restrict__ hq1,
+                                         unsigned (&K)[NK], long long &HqLo, long long &HqHi)
+{
+    static_for<gq_count<G, SET>()>([&](auto I) {
+        constexpr int p = I;
+        constexpr gp_pos A = gq_where<G, SET>(p, 0), B = gq_where<G, SET>(p, 1);
+        constexpr unsigned selx = (unsigned)(A.cx & 3) | (0x0cu << 8) | ((unsigned)(4 + (B.cx & 3)) << 16) | (0x0cu << 24);
+        constexpr unsigned sely = (unsigned)(A.cy & 3) | (0x0cu << 8) | ((unsigned)(4 + (B.cy & 3)) << 16) | (0x0cu << 24);
+        const unsigned x = __builtin_amdgcn_perm(P[B.rx][B.cx >> 2], P[A.rx][A.cx >> 2], selx);
+        const unsigned y = __builtin_amdgcn_perm(P[B.ry][B.cy >> 2], P[A.ry][A.cy >> 2], sely);
+        const unsigned lo = pk_min(x, y), hi = pk_max(x, y);
+        const unsigned d = pk_sub(hi, lo);
+        const unsigned one = 0x00010001u;
+        const unsigned diag = pk_sub_sat(one, d);
+        K[OFF + p] = ((lo << 8) | hi) | diag;
+        pin32(K[OFF + p]);
+        if constexpr (SPLIT) {   // d = 8 * dA | (8 * dB) << 16: byte offsets into the 32-entry table
+            HqLo += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq1) + (d & 0xffffu));
+            HqHi += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq1) + (d >> 16));
+        } else {
+            const unsigned off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, d), (us2){1, 32}, 0u, false);
+            HqLo += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq2) + off);
+        }
+        if constexpr (p % 6 == 5) { pin64(HqLo); pin64(HqHi); }
+    });
+}
+
+// one angle group of the four windows.  ED[s] = {E2, D} of slot s (both halves packed); Hq[w] of window w (A, B, C, D)
+template <int G>
+__device__ __forceinline__ void gq_group(const unsigned (&P)[8][2], const long long *__restrict__ hq2, const long long *__restrict__ hq1,
+                                         unsigned (&ED)[4][2], long long (&Hq)[4])
+{
+    constexpr int NC = gq_count<G, 0>(), NT = gq_count<G, 1>(), NO = gq_count<G, 3>(), NS = NC + NT, NK = NS + NO;
+    using QN = quad_holder<NC, NT, NO>;
+    unsigned KC[NC], KS[NS], K[NK];
+    long long hqCore = 0, dummy = 0;
+    gq_build<G, 0, 0, NC, false>(P, hq2, hq1, KC, hqCore, dummy);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<net_holder<NC>::net.n>([&](auto I) {
+        constexpr int ia = net_holder<NC>::net.a[I], ib = net_holder<NC>::net.b[I];
+        const unsigned ka = KC[ia], kb = KC[ib];
+        KC[ia] = pk_min(ka, kb);
+        KC[ib] = pk_max(ka, kb);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    long long stripLo[2] = {0, 0}, stripHi[2] = {0, 0}, ownLo[4] = {0, 0, 0, 0}, ownHi[4] = {0, 0, 0, 0};
+    auto half_block = [&](auto hb_t) {
+        constexpr int HB = decltype(hb_t)::value;     // 0: slots 0, 1 (strip set 1); 1: slots 2, 3 (strip set 2)
+        static_for<NC>([&](auto I) { KS[I] = KC[I]; });
+        gq_build<G, 1 + HB, NC, NS, true>(P, hq2, hq1, KS, stripLo[HB], stripHi[HB]);
+        static_for<net_holder<NT>::net.n>([&](auto I) {
+            constexpr int ia = NC + net_holder<NT>::net.a[I], ib = NC + net_holder<NT>::net.b[I];
+            const unsigned ka = KS[ia], kb = KS[ib];
+            KS[ia] = pk_min(ka, kb);
+            KS[ib] = pk_max(ka, kb);
+        });
+        static_for<QN::net.n1>([&](auto I) {
+            constexpr int ia = QN::net.a1[I], ib = QN::net.b1[I];
+            const unsigned ka = KS[ia], kb = KS[ib];
+            KS[ia] = pk_min(ka, kb);
+            KS[ib] = pk_max(ka, kb);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        auto slot = [&](auto s_t) {
+            constexpr int S = decltype(s_t)::value;
+            static_for<NS>([&](auto I) { K[I] = KS[I]; });
+            gq_build<G, 3 + S, NS, NK, true>(P, hq2, hq1, K, ownLo[S], ownHi[S]);
+            static_for<net_holder<NO>::net.n>([&](auto I) {
+                constexpr int ia = NS + net_holder<NO>::net.a[I], ib = NS + net_holder<NO>::net.b[I];
+                const unsigned ka = K[ia], kb = K[ib];
+                K[ia] = pk_min(ka, kb);
+                K[ib] = pk_max(ka, kb);
+            });
+            static_for<QN::net.n2>([&](auto I) {
+                constexpr int ia = QN::net.a2[I], ib = QN::net.b2[I];
+                const unsigned ka = K[ia], kb = K[ib];
+                K[ia] = pk_min(ka, kb);
+                K[ib] = pk_max(ka, kb);
+            });
+            const unsigned one = 0x00010001u;
+            unsigned E2 = 0, t = 0, D = K[QN::net.order2[0]] & one;
+            static_for<NK - 1>([&](auto I) {
+                constexpr int i = QN::net.order2[I + 1], j = QN::net.order2[I];
+                const unsigned diag = K[i] & one;
+                const unsigned eq = pk_sub_sat(one, K[i] ^ K[j]);
+                t = pk_mul(t + one + diag, eq);
+                E2 += t;
+                D += diag;
+            });
+            ED[S][0] = E2;
+            ED[S][1] = D;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        slot(std::integral_constant<int, 2 * HB>{});
+        slot(std::integral_constant<int, 2 * HB + 1>{});
+    };
+    half_block(std::integral_constant<int, 0>{});
+    half_block(std::integral_constant<int, 1>{});
+    if constexpr (G == 0) {   // low halves: 0 degrees of A, B, C, D; high halves: 90 degrees of A, C, B, D (the transpose partner)
+        Hq[0] = hqCore + stripLo[0] + stripHi[0] + ownLo[0] + ownHi[0];
+        Hq[1] = hqCore + stripLo[0] + stripHi[1] + ownLo[1] + ownHi[2];
+        Hq[2] = hqCore + stripLo[1] + stripHi[0] + ownLo[2] + ownHi[1];
+        Hq[3] = hqCore + stripLo[1] + stripHi[1] + ownLo[3] + ownHi[3];
+    } else {
+        Hq[0] = hqCore + stripLo[0] + stripHi[0] + ownLo[0] + ownHi[0];
+        Hq[1] = hqCore + stripLo[0] + stripHi[0] + ownLo[1] + ownHi[1];
+        Hq[2] = hqCore + stripLo[1] + stripHi[1] + ownLo[2] + ownHi[2];
+        Hq[3] = hqCore + stripLo[1] + stripHi[1] + ownLo[3] + ownHi[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k4_glcm_quad(const uint8_t *__restrict__ q, int H, int W, int oh, int ow, glcm_out out,
+                                                    glcm_consts gc)
+{
+    constexpr int SH = 3;
+    __shared__ long long hq2[1024];
+    __shared__ long long hq1[32];
+    for (int i = threadIdx.x; i < 1024; i += 256) hq2[i] = g_glcm_hq2[i];
+    if (threadIdx.x < 32) hq1[threadIdx.x] = c_glcm_hq[threadIdx.x];
+    __syncthreads();
+    const int ox = 2 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int oy = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (ox >= ow || oy >= oh) return;
+    const bool hasX = ox + 1 < ow, hasY = oy + 1 < oh;   // an odd map width / height leaves the last column / row of threads with fewer windows
+    unsigned P[8][2];
+    {
+        const uint8_t *wp = q + (size_t)oy * W + (size_t)ox;
+        static_for<8>([&](auto I) {
+            constexpr int r = I;
+            unsigned lo = 0, hi = 0;
+            static_for<8>([&](auto J) {
+                constexpr int c = J;
+                const unsigned b = ((c < 7 || hasX) && (r < 7 || hasY)) ? wp[(size_t)r * W + c] : 0u;
+                if constexpr (c < 4) lo |= b << (8 * c + SH);
+                else hi |= b << (8 * (c - 4) + SH);
+            });
+            P[r][0] = lo;
+            P[r][1] = hi;
+        });
+    }
+    unsigned ED[2][4][2];
+    long long Hq[2][4];
+#pragma nounroll
+    for (int g = 0; g < 2; g++) {
+        opaque_patch<8>(P);
+        if (g == 0) gq_group<0>(P, hq2, hq1, ED[0], Hq[0]);
+        else gq_group<1>(P, hq2, hq1, ED[1], Hq[1]);
+    }
+    // A = 2 (np + D) + 4 E2 per window and angle; group 0: window w's 0-degree statistics sit in the low half of slot w,
+    // its 90-degree statistics in the high half of its transpose partner's slot (A 0, B 2, C 1, D 3)
+    auto root_sum = [&](int pairs, unsigned e_lo, unsigned d_lo, unsigned e_hi, unsigned d_hi) {
+        const long long Aa = 2ll * (pairs + (int)(d_lo & 0xffffu)) + 4ll * (long long)(e_lo & 0xffffu);
+        const long long Ab = 2ll * (pairs + (int)(d_hi >> 16)) + 4ll * (long long)(e_hi >> 16);
+        return sqrt((double)Aa) + sqrt((double)Ab);
+    };
+#pragma nounroll
+    for (int wdw = 0; wdw < 4; wdw++) {
+        const int dx = wdw & 1, dy = wdw >> 1;
+        if ((dx && !hasX) || (dy && !hasY)) continue;
+        const int part = wdw == 1 ? 2 : (wdw == 2 ? 1 : wdw);
+        unsigned e0l = 0, d0l = 0, e0h = 0, d0h = 0, e1 = 0, d1 = 0;
+        long long h0 = 0, h1 = 0;
+        static_for<4>([&](auto I) {     // constant indices into the register arrays
+            constexpr int s = I;
+            if (wdw == s) { e0l = ED[0][s][0]; d0l = ED[0][s][1]; e1 = ED[1][s][0]; d1 = ED[1][s][1]; h0 = Hq[0][s]; h1 = Hq[1][s]; }
+            if (part == s) { e0h = ED[0][s][0]; d0h = ED[0][s][1]; }
+        });
+        const double sq0 = root_sum(42, e0l, d0l, e0h, d0h), sq1 = root_sum(36, e1, d1, e1, d1);
+        unsigned w[8][2];
+        opaque_patch<8>(P);
+        static_for<7>([&](auto I) {
+            constexpr int r = I;
+            unsigned a0 = 0, a1 = 0;
+            static_for<2>([&](auto DY) {    // rows r + dy with a constant index
+                if (dy == DY) { a0 = P[r + DY][0]; a1 = P[r + DY][1]; }
+            });
+            w[r][0] = dx ? __builtin_amdgcn_alignbyte(a1, a0, 1) : a0;
+            w[r][1] = dx ? (a1 >> 8) : (a1 & 0x00ffffffu);
+        });
+        w[7][0] = w[7][1] = 0;
+        gp_finish(w, h0, sq0, h1, sq1, (size_t)(oy + dy) * ow + (ox + dx), out, gc);
+    }
+}
+
 // one workgroup per window; LDS histogram of ordered cells [levels][levels]
 // One WAVE per window (levels <= 32, any window size < 256): the four angles' co-occurrence counts live in four private
 // 2 KB LDS tables of packed 16-bit counters (a window has fewer than 65536 pairs); no workgroup barrier anywhere — a wave's
@@ -924,8 +1224,14 @@ extern "C" int rsseg_glcm_u8(rsseg_ctx *ctx, const uint8_t *d_q, int H, int W, i
         else hipLaunchKernelGGL((k4_glcm_thread<WN, 2>), tg, dim3(256), 0, ctx->stream, d_q, H, W, step, oh, ow, out, gc);          \
     } while (0)
         if (win == 7 && step == 1 && levels <= 32) {
-            const dim3 pg((ow + 127) / 128, (oh + 3) / 4);   // two adjacent windows per thread
-            hipLaunchKernelGGL(k4_glcm_pair, pg, dim3(256), 0, ctx->stream, d_q, H, W, oh, ow, out, gc);
+            const char *kv = getenv("RSSEG_GLCM_DENSE");      // "pair": the r02 kernel (two windows per thread), for A/B runs
+            if (kv && !strcmp(kv, "pair")) {
+                const dim3 pg((ow + 127) / 128, (oh + 3) / 4);   // two adjacent windows per thread
+                hipLaunchKernelGGL(k4_glcm_pair, pg, dim3(256), 0, ctx->stream, d_q, H, W, oh, ow, out, gc);
+            } else {
+                const dim3 pg((ow + 127) / 128, (oh + 7) / 8);   // a 2 x 2 block of windows per thread
+                hipLaunchKernelGGL(k4_glcm_quad, pg, dim3(256), 0, ctx->stream, d_q, H, W, oh, ow, out, gc);
+            }
         } else if (win == 7) GLCM_THREAD(7);
         else if (win == 5) GLCM_THREAD(5);
         else if (win == 3) GLCM_THREAD(3);

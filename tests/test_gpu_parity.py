@@ -261,11 +261,24 @@ def test_glcm_other_level_counts_bitexact_vs_oracle(ctx, oracle, levels, win, st
         assert np.array_equal(host(g, (oh, ow)), want[k]), (k, levels, win, step)
 
 
-def test_glcm_dense_pair_kernel_edge_maps(ctx, oracle):
-    """Dense 7x7 / step 1 / 32 levels runs k4_glcm_pair (two adjacent windows per thread): maps of width 1, 2, 3 (a thread
-    with one window only), exactly one workgroup strip (128), one strip + 1 and + 2, single rows."""
+@pytest.fixture(params=["quad", "pair"])
+def dense_kernel(request):
+    """Dense 7x7 / step 1 / 32 levels: k4_glcm_quad (a 2 x 2 block of windows per thread, r04, the default) and
+    k4_glcm_pair (two adjacent windows per thread, r02; RSSEG_GLCM_DENSE=pair) — both must equal the oracle bit for bit."""
+    old = os.environ.get("RSSEG_GLCM_DENSE")
+    os.environ["RSSEG_GLCM_DENSE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("RSSEG_GLCM_DENSE", None)
+    else:
+        os.environ["RSSEG_GLCM_DENSE"] = old
+
+
+def test_glcm_dense_pair_kernel_edge_maps(ctx, oracle, dense_kernel):
+    """The dense kernels on maps of width / height 1, 2, 3 (threads with fewer windows than their block), exactly one
+    workgroup strip (128 windows wide, 8 rows tall), one strip + 1 and + 2, single rows and columns, odd and even sizes."""
     rng = np.random.default_rng(5)
-    for H, W in ((7, 7), (7, 8), (8, 9), (9, 134), (7, 135), (12, 136), (11, 20)):
+    for H, W in ((7, 7), (7, 8), (8, 7), (8, 8), (8, 9), (9, 134), (7, 135), (12, 136), (11, 20), (14, 21), (15, 263), (16, 13), (23, 7)):
         q = rng.integers(0, 32, (H, W)).astype(np.uint8)
         q[:, : W // 2] = (q[:, : W // 2] // 8) * 8   # few distinct levels on the left: many equal keys
         want = oracle.glcm_small_maps(q, 32, 7, 1, mode=1)
@@ -275,9 +288,9 @@ def test_glcm_dense_pair_kernel_edge_maps(ctx, oracle):
             assert np.array_equal(host(g, (oh, ow)), want[k]), (k, H, W)
 
 
-def test_glcm_dense_pair_kernel_bitexact_vs_oracle(ctx, oracle):
+def test_glcm_dense_pair_kernel_bitexact_vs_oracle(ctx, oracle, dense_kernel):
     """Dense 7x7 / step 1 / 32 levels on a map wider than one workgroup strip (128 windows) and taller than one
-    workgroup (4 rows): k4_glcm_pair against the oracle, all five properties bit for bit."""
+    workgroup (4 / 8 rows): the dense kernels against the oracle, all five properties bit for bit."""
     rng = np.random.default_rng(77)
     H, W = 150, 300
     base = rng.integers(0, 32, (H, W))
