@@ -168,7 +168,9 @@ def pattern_rate_gbs(family):
 def glcm_issue_cycles(glcm_step=1):
     """(weighted VALU issue cycles per wave, windows per wave, static VALU instructions per wave, kernel) of the texture
     kernel that runs at this step, from the committed microbenchmark summary; cycles None when it is absent."""
-    key, kern = ("glcm_pair", "k4_glcm_pair") if glcm_step == 1 else ("glcm_thread_7_3", "k4_glcm_thread<7,3>")
+    key, kern = ("glcm_quad", "k4_glcm_quad") if glcm_step == 1 else ("glcm_thread_7_3", "k4_glcm_thread<7,3>")
+    if glcm_step == 1 and os.environ.get("RSSEG_GLCM_DENSE") == "pair":
+        key, kern = "glcm_pair", "k4_glcm_pair"
     import glob
     try:
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue.json")))[-1]   # the newest round's histogram of the code object

@@ -45,5 +45,9 @@ out = {"source": "profiles/ubench/ubench.hip on MI355X + static histogram of the
        "glcm_thread_7_3": price(f"{ROUND}_glcm_thread_7_3_valu_hist.txt", 1),
        # window 7, step 1, levels <= 32: two adjacent windows per thread share the sort of their common keys
        "glcm_pair": price(f"{ROUND}_glcm_pair_valu_hist.txt", 2)}
+if os.path.exists(os.path.join(HERE, f"{ROUND}_glcm_quad_valu_hist.txt")):
+    # r04: a 2 x 2 block of windows per thread (histogram of the kernel compiled with its per-window finish loop unrolled, so
+    # that static counts are executed counts: profiles/valu_hist.sh)
+    out["glcm_quad"] = price(f"{ROUND}_glcm_quad_valu_hist.txt", 4)
 json.dump(out, open(os.path.join(HERE, f"{ROUND}_valu_issue.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -899,20 +899,22 @@ __device__ __forceinline__ void gq_build(const unsigned (&P)[8][2], const long l
             const unsigned off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, d), (us2){1, 32}, 0u, false);
             HqLo += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq2) + off);
         }
-        if constexpr (p % 6 == 5) { pin64(HqLo); pin64(HqHi); }
+        // table reads in flight: 6 pair-sum reads (core, built while few keys are live) or 3 x 2 per-half reads (12 registers)
+        if constexpr (SPLIT ? p % 3 == 2 : p % 6 == 5) { pin64(HqLo); pin64(HqHi); }
     });
 }
 
-// one angle group of the four windows.  ED[s] = {E2, D} of slot s (both halves packed); Hq[w] of window w (A, B, C, D)
+// one angle group of the four windows.  ED[s] = D + 2 E2 of slot s (both halves packed: at most 42 + 2 * 1722 per half, so
+// A = 2 (np + D) + 4 E2 = 2 (np + ED)); Hq[w] of window w (A, B, C, D)
 template <int G>
 __device__ __forceinline__ void gq_group(const unsigned (&P)[8][2], const long long *__restrict__ hq2, const long long *__restrict__ hq1,
-                                         unsigned (&ED)[4][2], long long (&Hq)[4])
+                                         unsigned (&ED)[4], long long (&Hq)[4])
 {
     constexpr int NC = gq_count<G, 0>(), NT = gq_count<G, 1>(), NO = gq_count<G, 3>(), NS = NC + NT, NK = NS + NO;
     using QN = quad_holder<NC, NT, NO>;
-    unsigned KC[NC], KS[NS], K[NK];
+    unsigned KC[NK], KS[NK], K[NK];    // KC: the sorted core (later core + strip 2, then slot 3 in place); KS: core + strip 1, then slot 1 in place
     long long hqCore = 0, dummy = 0;
-    gq_build<G, 0, 0, NC, false>(P, hq2, hq1, KC, hqCore, dummy);
+    gq_build<G, 0, 0, NK, false>(P, hq2, hq1, KC, hqCore, dummy);
     __builtin_amdgcn_sched_barrier(0);
     static_for<net_holder<NC>::net.n>([&](auto I) {
         constexpr int ia = net_holder<NC>::net.a[I], ib = net_holder<NC>::net.b[I];
@@ -921,73 +923,82 @@ __device__ __forceinline__ void gq_group(const unsigned (&P)[8][2], const long l
         KC[ib] = pk_max(ka, kb);
     });
     __builtin_amdgcn_sched_barrier(0);
-    long long stripLo[2] = {0, 0}, stripHi[2] = {0, 0}, ownLo[4] = {0, 0, 0, 0}, ownHi[4] = {0, 0, 0, 0};
-    auto half_block = [&](auto hb_t) {
-        constexpr int HB = decltype(hb_t)::value;     // 0: slots 0, 1 (strip set 1); 1: slots 2, 3 (strip set 2)
-        static_for<NC>([&](auto I) { KS[I] = KC[I]; });
-        gq_build<G, 1 + HB, NC, NS, true>(P, hq2, hq1, KS, stripLo[HB], stripHi[HB]);
+    // Hq of a window = core + its strip halves + its own halves.  Group 0 packs the 0-degree keys of window w with the
+    // 90-degree keys of its transpose partner: the low half of slot s belongs to window s, the high half to window
+    // part(s) = A, C, B, D; the low half of strip HB to windows 2 HB, 2 HB + 1 (a row strip), the high half to the windows of
+    // column HB (A, C / B, D).  Group 1: both halves of everything belong to the slot's own window / row of windows.
+    Hq[0] = Hq[1] = Hq[2] = Hq[3] = hqCore;
+    // core + strip HB, merged, in S (whose first NC registers hold the sorted core)
+    auto add_strip = [&](auto hb_t, unsigned (&S)[NK]) {
+        constexpr int HB = decltype(hb_t)::value;
+        long long lo = 0, hi = 0;
+        gq_build<G, 1 + HB, NC, NK, true>(P, hq2, hq1, S, lo, hi);
+        Hq[2 * HB] += lo;
+        Hq[2 * HB + 1] += lo;
+        if constexpr (G == 0) { Hq[HB] += hi; Hq[HB + 2] += hi; }
+        else { Hq[2 * HB] += hi; Hq[2 * HB + 1] += hi; }
         static_for<net_holder<NT>::net.n>([&](auto I) {
             constexpr int ia = NC + net_holder<NT>::net.a[I], ib = NC + net_holder<NT>::net.b[I];
-            const unsigned ka = KS[ia], kb = KS[ib];
-            KS[ia] = pk_min(ka, kb);
-            KS[ib] = pk_max(ka, kb);
+            const unsigned ka = S[ia], kb = S[ib];
+            S[ia] = pk_min(ka, kb);
+            S[ib] = pk_max(ka, kb);
         });
         static_for<QN::net.n1>([&](auto I) {
             constexpr int ia = QN::net.a1[I], ib = QN::net.b1[I];
-            const unsigned ka = KS[ia], kb = KS[ib];
-            KS[ia] = pk_min(ka, kb);
-            KS[ib] = pk_max(ka, kb);
+            const unsigned ka = S[ia], kb = S[ib];
+            S[ia] = pk_min(ka, kb);
+            S[ib] = pk_max(ka, kb);
         });
         __builtin_amdgcn_sched_barrier(0);
-        auto slot = [&](auto s_t) {
-            constexpr int S = decltype(s_t)::value;
-            static_for<NS>([&](auto I) { K[I] = KS[I]; });
-            gq_build<G, 3 + S, NS, NK, true>(P, hq2, hq1, K, ownLo[S], ownHi[S]);
-            static_for<net_holder<NO>::net.n>([&](auto I) {
-                constexpr int ia = NS + net_holder<NO>::net.a[I], ib = NS + net_holder<NO>::net.b[I];
-                const unsigned ka = K[ia], kb = K[ib];
-                K[ia] = pk_min(ka, kb);
-                K[ib] = pk_max(ka, kb);
-            });
-            static_for<QN::net.n2>([&](auto I) {
-                constexpr int ia = QN::net.a2[I], ib = QN::net.b2[I];
-                const unsigned ka = K[ia], kb = K[ib];
-                K[ia] = pk_min(ka, kb);
-                K[ib] = pk_max(ka, kb);
-            });
-            const unsigned one = 0x00010001u;
-            unsigned E2 = 0, t = 0, D = K[QN::net.order2[0]] & one;
-            static_for<NK - 1>([&](auto I) {
-                constexpr int i = QN::net.order2[I + 1], j = QN::net.order2[I];
-                const unsigned diag = K[i] & one;
-                const unsigned eq = pk_sub_sat(one, K[i] ^ K[j]);
-                t = pk_mul(t + one + diag, eq);
-                E2 += t;
-                D += diag;
-            });
-            ED[S][0] = E2;
-            ED[S][1] = D;
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        slot(std::integral_constant<int, 2 * HB>{});
-        slot(std::integral_constant<int, 2 * HB + 1>{});
     };
-    half_block(std::integral_constant<int, 0>{});
-    half_block(std::integral_constant<int, 1>{});
-    if constexpr (G == 0) {   // low halves: 0 degrees of A, B, C, D; high halves: 90 degrees of A, C, B, D (the transpose partner)
-        Hq[0] = hqCore + stripLo[0] + stripHi[0] + ownLo[0] + ownHi[0];
-        Hq[1] = hqCore + stripLo[0] + stripHi[1] + ownLo[1] + ownHi[2];
-        Hq[2] = hqCore + stripLo[1] + stripHi[0] + ownLo[2] + ownHi[1];
-        Hq[3] = hqCore + stripLo[1] + stripHi[1] + ownLo[3] + ownHi[3];
-    } else {
-        Hq[0] = hqCore + stripLo[0] + stripHi[0] + ownLo[0] + ownHi[0];
-        Hq[1] = hqCore + stripLo[0] + stripHi[0] + ownLo[1] + ownHi[1];
-        Hq[2] = hqCore + stripLo[1] + stripHi[1] + ownLo[2] + ownHi[2];
-        Hq[3] = hqCore + stripLo[1] + stripHi[1] + ownLo[3] + ownHi[3];
-    }
+    // slot S on the array X whose first NS registers hold core + strip (logical order: order1)
+    auto slot = [&](auto s_t, unsigned (&X)[NK]) {
+        constexpr int S = decltype(s_t)::value;
+        {
+            long long lo = 0, hi = 0;
+            gq_build<G, 3 + S, NS, NK, true>(P, hq2, hq1, X, lo, hi);
+            constexpr int PART = G == 0 ? (S == 1 ? 2 : (S == 2 ? 1 : S)) : S;
+            Hq[S] += lo;
+            Hq[PART] += hi;
+        }
+        static_for<net_holder<NO>::net.n>([&](auto I) {
+            constexpr int ia = NS + net_holder<NO>::net.a[I], ib = NS + net_holder<NO>::net.b[I];
+            const unsigned ka = X[ia], kb = X[ib];
+            X[ia] = pk_min(ka, kb);
+            X[ib] = pk_max(ka, kb);
+        });
+        static_for<QN::net.n2>([&](auto I) {
+            constexpr int ia = QN::net.a2[I], ib = QN::net.b2[I];
+            const unsigned ka = X[ia], kb = X[ib];
+            X[ia] = pk_min(ka, kb);
+            X[ib] = pk_max(ka, kb);
+        });
+        const unsigned one = 0x00010001u;
+        unsigned E2 = 0, t = 0, D = X[QN::net.order2[0]] & one;
+        static_for<NK - 1>([&](auto I) {
+            constexpr int i = QN::net.order2[I + 1], j = QN::net.order2[I];
+            const unsigned diag = X[i] & one;
+            const unsigned eq = pk_sub_sat(one, X[i] ^ X[j]);
+            t = pk_mul(t + one + diag, eq);
+            E2 += t;
+            D += diag;
+        });
+        ED[S] = D + (E2 << 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // slots 0, 1 from core + strip 1 (a copy of the core: the core itself is needed again); the last user of an array works in place
+    static_for<NC>([&](auto I) { KS[I] = KC[I]; });
+    add_strip(std::integral_constant<int, 0>{}, KS);
+    static_for<NS>([&](auto I) { K[I] = KS[I]; });
+    slot(std::integral_constant<int, 0>{}, K);
+    slot(std::integral_constant<int, 1>{}, KS);
+    add_strip(std::integral_constant<int, 1>{}, KC);
+    static_for<NS>([&](auto I) { K[I] = KC[I]; });
+    slot(std::integral_constant<int, 2>{}, K);
+    slot(std::integral_constant<int, 3>{}, KC);
 }
 
-__global__ __launch_bounds__(256) void k4_glcm_quad(const uint8_t *__restrict__ q, int H, int W, int oh, int ow, glcm_out out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k4_glcm_quad(const uint8_t *__restrict__ q, int H, int W, int oh, int ow, glcm_out out,
                                                     glcm_consts gc)
 {
     constexpr int SH = 3;
@@ -1016,7 +1027,7 @@ __global__ __launch_bounds__(256) void k4_glcm_quad(const uint8_t *__restrict__ 
             P[r][1] = hi;
         });
     }
-    unsigned ED[2][4][2];
+    unsigned ED[2][4];
     long long Hq[2][4];
 #pragma nounroll
     for (int g = 0; g < 2; g++) {
@@ -1026,24 +1037,30 @@ __global__ __launch_bounds__(256) void k4_glcm_quad(const uint8_t *__restrict__ 
     }
     // A = 2 (np + D) + 4 E2 per window and angle; group 0: window w's 0-degree statistics sit in the low half of slot w,
     // its 90-degree statistics in the high half of its transpose partner's slot (A 0, B 2, C 1, D 3)
-    auto root_sum = [&](int pairs, unsigned e_lo, unsigned d_lo, unsigned e_hi, unsigned d_hi) {
-        const long long Aa = 2ll * (pairs + (int)(d_lo & 0xffffu)) + 4ll * (long long)(e_lo & 0xffffu);
-        const long long Ab = 2ll * (pairs + (int)(d_hi >> 16)) + 4ll * (long long)(e_hi >> 16);
+    auto root_sum = [&](int pairs, unsigned ed_lo, unsigned ed_hi) {
+        const long long Aa = 2ll * (pairs + (int)(ed_lo & 0xffffu));
+        const long long Ab = 2ll * (pairs + (int)(ed_hi >> 16));
         return sqrt((double)Aa) + sqrt((double)Ab);
     };
+    // RSSEG_GLCM_COUNT_UNROLL (profiles/valu_hist.sh only): the loop unrolled, so that the STATIC instruction histogram of the
+    // code object equals the executed one (the shipped kernel keeps the loop rolled: one copy of the finish)
+#ifdef RSSEG_GLCM_COUNT_UNROLL
+#pragma unroll
+#else
 #pragma nounroll
+#endif
     for (int wdw = 0; wdw < 4; wdw++) {
         const int dx = wdw & 1, dy = wdw >> 1;
         if ((dx && !hasX) || (dy && !hasY)) continue;
         const int part = wdw == 1 ? 2 : (wdw == 2 ? 1 : wdw);
-        unsigned e0l = 0, d0l = 0, e0h = 0, d0h = 0, e1 = 0, d1 = 0;
+        unsigned e0l = 0, e0h = 0, e1 = 0;
         long long h0 = 0, h1 = 0;
         static_for<4>([&](auto I) {     // constant indices into the register arrays
             constexpr int s = I;
-            if (wdw == s) { e0l = ED[0][s][0]; d0l = ED[0][s][1]; e1 = ED[1][s][0]; d1 = ED[1][s][1]; h0 = Hq[0][s]; h1 = Hq[1][s]; }
-            if (part == s) { e0h = ED[0][s][0]; d0h = ED[0][s][1]; }
+            if (wdw == s) { e0l = ED[0][s]; e1 = ED[1][s]; h0 = Hq[0][s]; h1 = Hq[1][s]; }
+            if (part == s) e0h = ED[0][s];
         });
-        const double sq0 = root_sum(42, e0l, d0l, e0h, d0h), sq1 = root_sum(36, e1, d1, e1, d1);
+        const double sq0 = root_sum(42, e0l, e0h), sq1 = root_sum(36, e1, e1);
         unsigned w[8][2];
         opaque_patch<8>(P);
         static_for<7>([&](auto I) {
