@@ -228,8 +228,36 @@ def launch_ranks(n, argv):
                    RSSEG_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout is drained by a thread while ALL children are watched: a rank that dies (out of memory, a GPU fault)
+    # leaves the others inside a collective, so on the first non-zero exit — or when the overall limit expires — the rest are
+    # terminated (exact PIDs, started here) and the failure is returned instead of a hang
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("RSSEG_BENCH_LAUNCH_TIMEOUT", "3000"))
+    t_start = time.time()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() - t_start > limit:
+            failed = f"rank(s) {bad} failed" if bad else f"no result after {limit:.0f} s"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else ""
+    codes = [p.wait() for p in procs]
+    if failed:
+        print(f"bench.py: {failed}; the other ranks were stopped", file=sys.stderr)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:
@@ -249,6 +277,8 @@ def launch_selftest():
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     total = 1.0
+    if os.environ.get("RSSEG_SELFTEST_DIE_RANK") == str(rank):    # a rank that dies before the rendezvous (tests the launcher's watch)
+        return 7
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")

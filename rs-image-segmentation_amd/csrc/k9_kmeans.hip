@@ -1677,9 +1677,15 @@ int launch_lloyd(rsseg_ctx *ctx, bool update, int64_t nchunks, size_t lds, plane
                  int32_t *out32 = nullptr)
 {
     // out32: only the register-resident kernels (F <= 32) write the int32 plane themselves; lloyd_writes_int32() tells the caller
+    // float64 planes with 33 ... 64 clusters: the register-resident kernels for 9 ... 32 planes need more than 512 registers
+    // (252 - 628 bytes of scratch per lane in the r03 code object) — the feature-blocked kernel below holds one
+    // block of planes at a time and does not spill at any size (346 - 370 registers), same arithmetic, same bits
+    constexpr bool wide64 = std::is_same<T, double>::value && KMAX == 64;
     if (F <= 8) return launch_lloyd2<T, KMAX, 8>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
-    if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
-    if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
+    if (!wide64) {
+        if (F <= 16) return launch_lloyd2<T, KMAX, 16>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
+        if (F <= 32) return launch_lloyd2<T, KMAX, 32>(ctx, update, nchunks, lds, pl, F, k, n, sp, cenT, csq, labels, partial, ncopies, done, out32);
+    }
     // 32 < F <= RSSEG_MAX_FEATURES: the feature-blocked kernel
     if (update) {
         static std::mutex mu;
@@ -1797,14 +1803,25 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     const size_t pin_need = std::max<size_t>({sizeof(T) * 2 * (size_t)nblk * F, sizeof(long long) * (size_t)nblk * F + sizeof(double) * RSSEG_MAX_FEATURES + 64,
                                               sizeof(long long) * (size_t)std::max(KPP_MAXL, F + 1) * (size_t)nchunks, sizeof(T) * (size_t)CHUNK,
                                               sizeof(long long) * 2 * (size_t)M + sizeof(km_state<T>), (size_t)65536});
-    // small host-to-device uploads (candidate rows, centres) go through a ring of pinned slots behind the read-back area:
-    // the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came from dies
-    // (a slot is reused four uploads later; every k-means++ round and every Lloyd iteration synchronises in between)
+    // small host-to-device uploads (the state, centres of the host-side iterations) go through a ring of 4 pinned slots behind
+    // the read-back area: the copy is then asynchronous for real and needs no synchronisation before the stack buffer it came
+    // from dies.  Invariant: a slot is reused only after a host synchronisation since its last use — the device-resident
+    // loop makes at most two uploads between two waits today, and the ring enforces it: a fifth upload without a wait in
+    // between (ctx->host_syncs is the epoch) waits for the stream first.
     constexpr size_t UP_SLOT = 64 * 1024;
     const size_t pin_main = (pin_need + 255) & ~(size_t)255;
     RSCHK(pin_reserve(ctx, pin_main + 4 * UP_SLOT));
-    unsigned up_i = 0;
+    unsigned up_i = 0, up_since_sync = 0;
+    long long up_epoch = ctx->host_syncs;
     auto upload = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (ctx->host_syncs != up_epoch) { up_epoch = ctx->host_syncs; up_since_sync = 0; }
+        if (up_since_sync == 4) {          // every slot is (possibly) still being copied
+            const hipError_t e = rs_sync(ctx);
+            if (e != hipSuccess) return e;
+            up_epoch = ctx->host_syncs;
+            up_since_sync = 0;
+        }
+        up_since_sync++;
         char *slot = ctx->h_pin + pin_main + (size_t)(up_i++ & 3u) * UP_SLOT;
         memcpy(slot, src, bytes);
         return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -2284,7 +2301,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     }
     // the final E-step (labels of the final centres; skipped when the last iteration changed no label) writes the caller's
     // int32 plane itself when its kernel can (F <= 32, 16-byte aligned plane); otherwise the uint8 plane is widened
-    const bool direct = !strict && F <= 32 && n > 0 && ((uintptr_t)d_labels & 15) == 0;
+    const bool direct = !strict && n > 0 && ((uintptr_t)d_labels & 15) == 0 && (F <= 8 || (F <= 32 && !(std::is_same<T, double>::value && KMAX == 64)));
     if (!strict) RSCHK(run_lloyd(false, false, true, direct ? d_labels : nullptr));
     if (n > 0 && !direct) {
         prof_scope ps(ctx, "labels");

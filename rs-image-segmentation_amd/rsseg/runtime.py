@@ -177,10 +177,18 @@ class Context:
         self._chk(self.lib.rsseg_ctx_set_comm(self.h, self.rank, self.world, self._hook, None,
                                               C.c_void_p(self._comm_buf.data_ptr()), self._comm_buf.numel()))
 
+    def _needs_keep(self) -> bool:
+        """A temporary dropped by Python goes back to torch's caching allocator, which reuses it in the order of the stream
+        it was ALLOCATED on (torch's current stream).  When that is this context's stream — the default — queued kernels
+        that still read the block run before anything that could overwrite it, so nothing has to be kept alive and the
+        pipelines free their temporaries as they go (keeping everything until end_async() raised the peak by
+        several planes).  Only a context on a side stream (aux()) must hold on to them until sync()."""
+        return getattr(self, "_async", False) and self.torch_stream != _torch().cuda.current_stream(self.device)
+
     def set_async(self, on: bool = True):
-        """Asynchronous entry points.  Buffers handed out by empty() are then kept alive until sync(): the
+        """Asynchronous entry points.  On a side stream, buffers handed out by empty() are kept alive until sync(): the
         caching allocator would otherwise recycle a temporary the moment Python drops it, while kernels that
-        read it are still queued on this context's stream."""
+        read it are still queued on this context's stream (_needs_keep)."""
         self._chk(self.lib.rsseg_ctx_set_async(self.h, int(on)))
         self._async = bool(on)
         self._keep = []
@@ -256,7 +264,7 @@ class Context:
         """uint8 plane -> float32 plane (exact), rsseg_u8_to_f32."""
         torch = _torch()
         out = self.empty(q.numel(), torch.float32)
-        if getattr(self, "_async", False):
+        if self._needs_keep():
             self._keep.append(q)
         self._chk(self.lib.rsseg_u8_to_f32(self.h, C.c_void_p(q.data_ptr()), q.numel(), C.c_void_p(out.data_ptr())))
         return out
@@ -279,7 +287,7 @@ class Context:
     def empty(self, n, dtype):
         torch = _torch()
         t = torch.empty(int(n), dtype=dtype, device=self.device)
-        if getattr(self, "_async", False):
+        if self._needs_keep():
             self._keep.append(t)
         return t
 

@@ -568,6 +568,25 @@ def test_kmeans_corner_sizes(ctx, oracle, n, F, k):
     assert np.array_equal(host(labels), want)
 
 
+@pytest.mark.parametrize("n,F,k", [(400, 12, 40), (600, 20, 64), (300, 5, 64), (500, 31, 33)])
+def test_kmeans_float64_planes_with_more_than_32_clusters(ctx, oracle, n, F, k):
+    """float64 planes, 33 ... 64 clusters: 9 ... 32 planes take the feature-blocked Lloyd kernel (the register-resident form
+    would need scratch memory there), up to 8 planes the register-resident one; labels, seeds and iteration
+    count against the oracle, and the float32 twin of the same data for comparison of the code paths."""
+    rng = np.random.default_rng(n + F + k)
+    centres = rng.random((k, F))
+    planes = [np.ascontiguousarray((centres[rng.integers(0, k, n), f] + rng.normal(0, 0.02, n))) for f in range(F)]
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    labels, meta = ctx.kmeans_fit_predict([dev(ctx, p) for p in planes], k)
+    assert planes[0].dtype == np.float64 and meta["n_iter"] == info["n_iter"]
+    assert np.array_equal(meta["init_indices"], info["init_indices"])
+    assert np.array_equal(host(labels), want)
+    p32 = [p.astype(np.float32) for p in planes]
+    want32, info32 = oracle.kmeans_fit_planes(p32, k)
+    labels32, meta32 = ctx.kmeans_fit_predict([dev(ctx, p) for p in p32], k)
+    assert meta32["n_iter"] == info32["n_iter"] and np.array_equal(host(labels32), want32)
+
+
 def test_kmeans_errors(ctx):
     x = dev(ctx, np.zeros(3, np.float32))
     with pytest.raises(ValueError):

@@ -336,6 +336,18 @@ def test_bench_reports_a_failed_rank():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """One rank exits before the rendezvous, the others wait in it for ever: the launcher notices the dead child, stops the
+    rest and returns non-zero within seconds (it used to block in rank 0's communicate())."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "3", "--launch-selftest", env={"RSSEG_SELFTEST_DIE_RANK": "2"})
+    assert r.returncode != 0 and "failed" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 120
+    r = _bench("--gpus", "2", "--launch-selftest", env={"RSSEG_SELFTEST_DIE_RANK": "0"})      # rank 0 itself
+    assert r.returncode != 0
+
+
 # ---- the star-import surface (SURVEY.md 8b): `from modules.features.indices import *` (scripts/2:20) and
 # `from modules.features.extract import *` (scripts/3:25) are how the reference's scripts reach the path ----
 OUT_OF_SCOPE_LIBRARY_NAMES = {"plt", "cv2"}     # matplotlib / OpenCV modules the reference leaks through import *: not re-exported
