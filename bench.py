@@ -123,12 +123,12 @@ MFMA_UTIL = {"value": 0.0, "note": "no MFMA instruction in the step (SQ_VALU_MFM
                                    "DESIGN.md 5: an MFMA accumulates in floating point, and even at the f64 matrix peak the 16 x 16 x 4 tiles of a 7-band Gram (137 GFLOP padded) take 1.75 ms against 1.3 ms for the kernel that exists"}
 
 # dominant kernel of a family in profiles/*_pmc_traffic.json (rocprofv3 --pmc passes)
-PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_pair",
+PMC_KERNEL = {"lloyd": "km_lloyd<float, 8, 16, true>", "kpp": "km_kpp<float, 4, 16, 2>", "glcm": "k4_glcm_quad",
               "select": "k1_hist<3, 1024, 4>", "indices": "k2_indices<true", "gram": "k3_gram<7", "project": "k3_project<7, true", "indices_project": "k3_indices_project<7, true",
               "resize": "k5_resize<true>", "forest": "k11_forest", "ctxmean": "k6_box<7, false>"}
 # static VALU instructions of the texture kernels and their measured issue cost (profiles/valu_mix.py ->
 # profiles/r*_valu_issue.json, the newest): the bound of the texture kernel is VALU issue, not HBM.  Dense case (window 7, step 1):
-# k4_glcm_pair, 128 windows per wave; other steps: k4_glcm_thread<7,3>, 64 windows per wave.
+# k4_glcm_quad, 256 windows per wave (r02 / r03: k4_glcm_pair, 128); other steps: k4_glcm_thread<7,3>, 64 windows per wave.
 GLCM_VALU = {"insts_per_wave": 2954, "issue_cycles_per_wave": None}
 
 
