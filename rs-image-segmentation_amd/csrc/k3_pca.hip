@@ -334,7 +334,26 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
         lmn[slot] = fminf(lmn[slot], z);
         lmx[slot] = fmaxf(lmx[slot], z);
     };
-    auto body = [&](int64_t i) {
+    // ONE loop for both workgroup -> pixel mappings (no lambda around the body: a closure that captures the extrema arrays
+    // by reference keeps them in scratch memory — 64 - 128 B per lane, +5 ... +14 B/px of HBM traffic in the r04 PMC tables).
+    // chunked: a workgroup owns contiguous chunks of FUSE_CHUNK_V 16-byte vectors (16 tiles of 1024 px, the k-means kernels'
+    // mapping): with 7 planes read and 11 written, 18 streams per workgroup, the bare pattern runs 3.26 ms in this mapping
+    // against 3.66-3.72 ms grid-strided at 16384^2 (profiles/r04_streams_write_heavy.json)
+    const int64_t nchunk = (n4 + FUSE_CHUNK_V - 1) / FUSE_CHUNK_V;
+    int64_t cur_chunk = blockIdx.x, gi = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
+    int cur_t = 0;
+    for (;;) {
+        int64_t i;
+        if (chunked) {
+            if (cur_chunk >= nchunk) break;
+            i = cur_chunk * FUSE_CHUNK_V + (int64_t)cur_t * PCA_THREADS + threadIdx.x;
+            if (++cur_t == FUSE_CHUNK_V / PCA_THREADS) { cur_t = 0; cur_chunk += gridDim.x; }
+            if (i >= n4) continue;
+        } else {
+            if (gi >= n4) break;
+            i = gi;
+            gi += (int64_t)gridDim.x * PCA_THREADS;
+        }
         float nbv[4][5], x[4][NB];
         if (U8) {
             uint32_t w[NB];
@@ -398,22 +417,6 @@ __global__ __launch_bounds__(PCA_THREADS) void k3_indices_project(pca_args a, pr
                     }
             }
         }
-    };
-    if (chunked) {
-        // a workgroup owns contiguous chunks of FUSE_CHUNK_V 16-byte vectors (16 tiles of 1024 px, the k-means kernels' mapping):
-        // with 7 planes read and 11 written, 18 streams per workgroup, the bare pattern runs 3.26 ms in this mapping against
-        // 3.66-3.72 ms grid-strided at 16384^2 (profiles/r04_streams_write_heavy.json)
-        const int64_t nchunk = (n4 + FUSE_CHUNK_V - 1) / FUSE_CHUNK_V;
-        for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-            const int64_t i0 = c * FUSE_CHUNK_V + threadIdx.x;
-#pragma unroll 1
-            for (int t = 0; t < FUSE_CHUNK_V / PCA_THREADS; t++) {
-                const int64_t i = i0 + (int64_t)t * PCA_THREADS;
-                if (i < n4) body(i);
-            }
-        }
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCA_THREADS) body(i);
     }
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * PCA_THREADS + threadIdx.x;
     if (t < n) {

@@ -899,8 +899,9 @@ __device__ __forceinline__ void gq_build(const unsigned (&P)[8][2], const long l
             const unsigned off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, d), (us2){1, 32}, 0u, false);
             HqLo += *reinterpret_cast<const long long *>(reinterpret_cast<const char *>(hq2) + off);
         }
-        // table reads in flight: 6 pair-sum reads (core, built while few keys are live) or 3 x 2 per-half reads (12 registers)
-        if constexpr (SPLIT ? p % 3 == 2 : p % 6 == 5) { pin64(HqLo); pin64(HqHi); }
+        // table reads in flight: 6 pair-sum reads (core, built while few keys are live) or 2 x 2 per-half reads (8 registers:
+        // the own-key sets are built at the kernel's register peak)
+        if constexpr (SPLIT ? p % 2 == 1 : p % 6 == 5) { pin64(HqLo); pin64(HqHi); }
     });
 }
 
@@ -1007,10 +1008,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = threadIdx.x; i < 1024; i += 256) hq2[i] = g_glcm_hq2[i];
     if (threadIdx.x < 32) hq1[threadIdx.x] = c_glcm_hq[threadIdx.x];
     __syncthreads();
-    const int ox = 2 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int oy = 2 * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    // The window coordinates are needed at the two ends of the kernel only.  Kept in vector registers they (or the thread id
+    // they come from) were spilled to scratch memory at the 168-register budget: 3 dwords per thread, +2 B/px of HBM writes in
+    // the PMC table.  So they are DERIVED twice from values that cost no vector register in between: the wave's index in
+    // the workgroup (uniform: a scalar register) and the lane index (v_mbcnt).
+    int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6;
+    auto coords = [&](int &ox_, int &oy_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(wave_s));        // opaque: not merged with the other derivation
+#endif
+        unsigned zero = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(zero));
+#endif
+        const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+        ox_ = 2 * ((int)blockIdx.x * 64 + lane_);
+        oy_ = 2 * ((int)blockIdx.y * 4 + wave_s);
+    };
+    int ox, oy;
+    coords(ox, oy);
     if (ox >= ow || oy >= oh) return;
-    const bool hasX = ox + 1 < ow, hasY = oy + 1 < oh;   // an odd map width / height leaves the last column / row of threads with fewer windows
+    bool hasX = ox + 1 < ow, hasY = oy + 1 < oh;   // an odd map width / height leaves the last column / row of threads with fewer windows
     unsigned P[8][2];
     {
         const uint8_t *wp = q + (size_t)oy * W + (size_t)ox;
@@ -1037,6 +1055,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     // A = 2 (np + D) + 4 E2 per window and angle; group 0: window w's 0-degree statistics sit in the low half of slot w,
     // its 90-degree statistics in the high half of its transpose partner's slot (A 0, B 2, C 1, D 3)
+    coords(ox, oy);
+    hasX = ox + 1 < ow;
+    hasY = oy + 1 < oh;
     auto root_sum = [&](int pairs, unsigned ed_lo, unsigned ed_hi) {
         const long long Aa = 2ll * (pairs + (int)(ed_lo & 0xffffu));
         const long long Ab = 2ll * (pairs + (int)(ed_hi >> 16));
