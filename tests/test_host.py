@@ -377,6 +377,12 @@ def test_star_import_resolves_every_name_the_reference_scripts_use(golden_dir, s
             assert callable(ns[n]) and ns[n].__module__ == mirror, n
     assert set(mod.PLOTTING_NAMES) == {n for n in mod.__all__ if n in PLOT_NAMES | {"visualize_selected_features"}}
     assert (wanted & PLOT_NAMES) <= set(mod.PLOTTING_NAMES)
+    for n in mod.PLOTTING_NAMES:          # resolve, print a line, draw and write nothing
+        import inspect
+        args = [None] * sum(p.default is inspect.Parameter.empty for p in inspect.signature(ns[n]).parameters.values())
+        assert ns[n](*args) is None
+    from modules.utils.set_chinese_font import set_chinese_font       # scripts/2:22, scripts/3:16
+    assert set_chinese_font() is None
 
 
 def test_mirror_signatures_equal_the_reference_for_every_mirrored_function(golden_dir):
