@@ -109,10 +109,21 @@ class Context:
         self.comm_kind = None
         if use_dist and (dist.get_world_size(group) > 1 or force_comm):
             kind = comm or os.environ.get("RSSEG_COMM") or ("native" if dist.get_backend(group) == "nccl" else "torch")
+            if kind == "native-only":
+                kind = "native"
             if kind not in ("native", "torch"):
                 raise ValueError(f"comm={kind!r}: 'native' or 'torch'")
             if kind == "native":
-                self._install_comm_rccl(group)
+                try:
+                    self._install_comm_rccl(group)
+                except (RssegError, OSError) as e:
+                    # a failure every rank meets alike (librccl not loadable, a symbol missing, ncclCommInitRank refusing the
+                    # topology): fall back to the callback provider LOUDLY rather than lose the run; RSSEG_COMM=native-only forbids it
+                    if os.environ.get("RSSEG_COMM") == "native-only" or comm == "native":
+                        raise
+                    print(f"[rsseg] native RCCL provider unavailable ({e}); using the torch.distributed callback", flush=True)
+                    kind = "torch"
+                    self._install_comm(group)
             else:
                 self._install_comm(group)
             self.comm_kind = kind
