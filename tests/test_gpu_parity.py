@@ -335,7 +335,12 @@ def test_glcm_vs_skimage_docstring_image_and_literal_restatement(ctx, oracle):
 
 def test_resize_bilinear_bitexact_vs_oracle(ctx, oracle):
     rng = np.random.default_rng(5)
-    for (sh, sw, dh, dw) in [(28, 28, 600, 600), (13, 7, 40, 55), (594, 594, 600, 600), (1, 1, 8, 8), (5, 9, 5, 9)]:
+    # up-sampling by 21 (config 5's maps), by ~1 (config 3's), mixed, a 1 x 1 source, the identity; r04 (the kernel walks
+    # SOURCE rows, several destination rows per source row or none): down-sampling by 6 / 4.4 / 1.003, a source row count
+    # below the look-ahead, and destination strips taller than one workgroup's share
+    for (sh, sw, dh, dw) in [(28, 28, 600, 600), (13, 7, 40, 55), (594, 594, 600, 600), (1, 1, 8, 8), (5, 9, 5, 9),
+                             (600, 600, 100, 90), (57, 33, 13, 40), (300, 300, 299, 301), (40, 40, 2000, 300), (3, 500, 700, 20),
+                             (1000, 16, 3, 16), (2, 2, 1, 1)]:
         src = rng.random((sh, sw)).astype(np.float32)
         got = host(ctx.resize_bilinear(dev(ctx, src), sh, sw, dh, dw), (dh, dw))
         assert np.array_equal(got, oracle.resize_bilinear(src, dh, dw)), (sh, sw, dh, dw)
