@@ -96,11 +96,12 @@ def synth_rows(torch, device, W, g0, g1, want=range(7), bands=7, kind="easy"):
 # ---- roofline bookkeeping --------------------------------------------------------------------------------------------
 def family_table(cfg, F, glcm_step, k, n_pca):
     """kernel family -> (bound, algorithmic HBM bytes per pixel and launch) — SURVEY.md §8(d), DESIGN.md §5.
-    'lloyd' is charged the bytes it moves (F float32 planes + uint8 label read + write), not int32 labels."""
+    'lloyd' is charged the F float32 planes an update sweep reads (r04: the sweeps of the device-resident loop keep no label
+    plane; the final E-step, one launch in seven here, also writes 4 B/px of int32 labels)."""
     idx_out = 7 * 4 + (4 if cfg in ("c3", "c5") else 0)   # + the normalised NIR band the texture chain reads
     return {
         "kpp": ("hbm", (4 * F * k + 4 + 8 * max(k - 2, 0)) / max(k, 1)),   # k passes: F planes in, closest plane r/w from round 2 on
-        "lloyd": ("hbm", 4 * F + 2),
+        "lloyd": ("hbm", 4 * F),
         "moment": ("hbm", 4 * F),                                          # column means of the scaled matrix: F planes in
         "labels": ("hbm", 5),                                              # uint8 labels in, int32 labels out
         "select": ("hbm", 4),                                              # one radix pass over one float32 plane
@@ -159,7 +160,7 @@ def pattern_rate_gbs(family):
         if family == "select":            # one float32 plane read once: the small-integer pass at its best grid (r04_k1_sweep.json) is the pattern
             return round(max(r["read_only"]["1"] for r in json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]) * 1000.0, 1)
         runs = json.load(open(os.path.join(ROOT, "profiles", "r02_streams.json")))["runs"]
-        key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("with_rw_plane", "15"), "moment": ("read_only", "1")}[family]
+        key, ns = {"kpp": ("with_rw_plane", "15"), "lloyd": ("read_only", "15"), "moment": ("read_only", "1")}[family]
         return round(max(r[key][ns] for r in runs if key in r) * 1000.0, 1)
     except Exception:  # noqa: BLE001
         return None

@@ -585,6 +585,8 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd(planes_t pl, int F, int k
                 for (int p = 0; p < PXL; p++)
                     if (base + p < n) out32[base + p] = lab[p];
             }
+        } else if (!labels) {
+            my_changed = 1;   // untracked sweep (see kmeans_fit): "some label changed" as far as the stopping rules go
         } else if (FULL || base + PXL <= n) {
             if constexpr (PXL == 4) {
                 uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
@@ -902,7 +904,9 @@ __global__ __launch_bounds__(KM_THREADS) void km_lloyd_blk(planes_t pl, int F, i
             }
             lab[p] = bl;
         }
-        if (FULL || base + PXL <= n) {
+        if (!labels) {
+            my_changed = 1;   // untracked sweep
+        } else if (FULL || base + PXL <= n) {
             if constexpr (PXL == 4) {
                 uchar4 old = *reinterpret_cast<const uchar4 *>(labels + base);
                 my_changed += (old.x != lab[0]) + (old.y != lab[1]) + (old.z != lab[2]) + (old.w != lab[3]);
@@ -2051,7 +2055,15 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     if (lds > 150 * 1024) return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "kmeans: F=%d, k=%d needs %zu B of LDS", F, k, lds);
     // one E-step (+ per-cluster sums when `update`).  from_state: the centres come from the device state (kl_prepare builds
     // their transposed copy and norms; `done`-guarded unless forced); otherwise from the host array C.
-    auto run_lloyd = [&](bool update, bool from_state, bool force, int32_t *out32 = nullptr) -> int {
+    // track: the sweep reads the previous labels of the uint8 working plane, counts the changes and writes the new ones.
+    // The device-resident loop runs its update sweeps UNTRACKED (r04): "no label changed" only lets sklearn skip the final
+    // E-step — with centres that are exact integer sums / counts, equal labels give bit-equal centres, so the shift is
+    // exactly 0 <= tol and the loop ends in the SAME iteration through the tolerance rule, and the final E-step it then runs
+    // reproduces those labels (they are argmin of the same centres): same labels, same n_iter, one more E-step in the
+    // strictly converged case, and every update sweep loses its read-modify-write plane (62 -> 60 B/px and a read-only
+    // stream: 2.9 -> 2.6 ms at 16384^2).  The host-side loop (empty clusters: relocation makes the centres depend on more
+    // than the labels) keeps tracking.
+    auto run_lloyd = [&](bool update, bool from_state, bool force, int32_t *out32 = nullptr, bool track = true) -> int {
         if (from_state) {
             // d_cen already holds the transposed centres of the state: kl_prepare before the first iteration, kl_update after each
         } else {
@@ -2075,12 +2087,13 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
             {
                 prof_scope ps(ctx, "lloyd");
                 const size_t l2 = update ? lds : 0;
+                uint8_t *lab_arg = (update && !track) ? nullptr : d_lab;
                 int lrc;
                 switch (KMAX) {
-                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
-                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
-                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
-                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, d_lab, d_part, ncopies, dflag, out32); break;
+                case 8: lrc = launch_lloyd<T, 8>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, lab_arg, d_part, ncopies, dflag, out32); break;
+                case 16: lrc = launch_lloyd<T, 16>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, lab_arg, d_part, ncopies, dflag, out32); break;
+                case 32: lrc = launch_lloyd<T, 32>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, lab_arg, d_part, ncopies, dflag, out32); break;
+                default: lrc = launch_lloyd<T, 64>(ctx, update, nchunks, l2, pl, F, k, n, d_sp, d_cen, d_csq, lab_arg, d_part, ncopies, dflag, out32); break;
                 }
                 if (lrc != RSSEG_OK) return lrc;
             }
@@ -2089,7 +2102,6 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
         return RSSEG_OK;
     };
 
-    if (n > 0) HIPCHK(ctx, hipMemsetAsync(d_lab, 0xFF, (size_t)n, st));
     bool strict = false;
     int it = 0, relocated = 0;
     std::vector<long long> red((size_t)2 * M);
@@ -2229,7 +2241,7 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     while (!finished && !host_mode) {
         const int todo = std::min(batch, max_iter - it);
         for (int b = 0; b < todo; b++) {
-            RSCHK(run_lloyd(true, true, false));
+            RSCHK(run_lloyd(true, true, false, nullptr, false));
             hipLaunchKernelGGL(km_reduce_cols, dim3(M), dim3(KM_THREADS), 0, st, (const long long *)d_part, nchunks, d_sums, (const int *)&d_lst->done, 1, 0);
             HIPCHK(ctx, hipGetLastError());
             if (ctx->comm_on) {   // stream-ordered: no staging copy, no host synchronisation (include/rsseg.h, rsseg_allreduce_fn)
@@ -2280,7 +2292,11 @@ int kmeans_fit(rsseg_ctx *ctx, const void *const *d_planes, int F, int64_t n, in
     }
     if (host_mode) {
         // the iteration in which a cluster ran empty: its E-step and its (all-reduced) sums exist, the centres the kernels
-        // used (d_cen) are still those of that E-step — finish it here, then iterate on the host
+        // used (d_cen) are still those of that E-step — finish it here, then iterate on the host.  The untracked sweeps wrote
+        // no labels: the relocation (distance to the ASSIGNED centre) and the tracked iterations that follow need them, so
+        // that E-step is repeated once, labels only.  (Its change count is known to be non-zero: a cluster that holds
+        // pixels in one iteration and none in the next has lost them.)
+        RSCHK(run_lloyd(false, true, true));
         int end = host_finish_iteration();
         if (end < 0) return end;
         while (!end) {
