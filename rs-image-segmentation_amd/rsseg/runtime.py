@@ -193,8 +193,12 @@ class Context:
         it was ALLOCATED on (torch's current stream).  When that is this context's stream — the default — queued kernels
         that still read the block run before anything that could overwrite it, so nothing has to be kept alive and the
         pipelines free their temporaries as they go (keeping everything until end_async() raised the peak by
-        several planes).  Only a context on a side stream (aux()) must hold on to them until sync()."""
-        return getattr(self, "_async", False) and self.torch_stream != _torch().cuda.current_stream(self.device)
+        several planes).  Only a context on a side stream (aux()), or one that has handed work to such a stream, must hold on to them until sync()."""
+        if not getattr(self, "_async", False):
+            return False
+        if getattr(self, "_aux", None) is not None:
+            return True     # a second stream allocates from the same pool: a block freed here could be rewritten there too early
+        return self.torch_stream != _torch().cuda.current_stream(self.device)
 
     def set_async(self, on: bool = True):
         """Asynchronous entry points.  On a side stream, buffers handed out by empty() are kept alive until sync(): the

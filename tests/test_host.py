@@ -385,6 +385,22 @@ def test_star_import_resolves_every_name_the_reference_scripts_use(golden_dir, s
     assert set_chinese_font() is None
 
 
+def test_names_fixture_is_what_the_generator_makes_today(golden_dir, tmp_path):
+    """Build container only (skipped where /root/reference does not exist, e.g. on the GPU box): oracle/gen_names.py re-run on the
+    reference gives the committed fixture."""
+    import json
+    import subprocess
+    import sys as _sys
+    if not os.path.isdir("/root/reference/scripts"):
+        pytest.skip("the reference is not present here")
+    src = open(os.path.join(ROOT, "oracle", "gen_names.py")).read().replace('OUT = os.path.join(REPO, "tests", "golden", "star_import_names.json")',
+                                                                            f'OUT = {str(tmp_path / "names.json")!r}')
+    gen = tmp_path / "gen_names_tmp.py"
+    gen.write_text(src)
+    subprocess.check_call([_sys.executable, str(gen)], stdout=subprocess.DEVNULL)
+    assert json.load(open(tmp_path / "names.json")) == json.load(open(os.path.join(golden_dir, "star_import_names.json")))
+
+
 def test_mirror_signatures_equal_the_reference_for_every_mirrored_function(golden_dir):
     """Positional order and defaults of every function both modules define, against the signature strings the fixture
     holds (names and default literals only)."""
