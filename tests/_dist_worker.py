@@ -147,6 +147,19 @@ def main():
             raise AssertionError("a range beyond the communication buffer was accepted")
         except ValueError:
             pass
+        # argument checks of the native provider (no communicator is created by any of these)
+        import ctypes as C
+        bad = Context(0, use_dist=False)
+        uid = (C.c_char * 128)()
+        assert bad.lib.rsseg_rccl_unique_id(None, C.cast(uid, C.c_void_p)) == 0          # NULL path: librccl.so.1 as the process has it
+        assert bad.lib.rsseg_ctx_set_comm_rccl(bad.h, 0, 1, None, None, None, 0) == -1                           # no unique id
+        assert bad.lib.rsseg_ctx_set_comm_rccl(bad.h, 3, 2, C.cast(uid, C.c_void_p), None, None, 0) == -1        # rank outside the world
+        assert bad.lib.rsseg_ctx_set_comm_rccl(bad.h, 0, 1, C.cast(uid, C.c_void_p), None, C.c_void_p(nbuf.data_ptr()), 4096) == -1   # buffer < 1 MiB
+        assert bad.lib.rsseg_ctx_set_comm_rccl(bad.h, 0, 1, C.cast(uid, C.c_void_p), None, None, 0) == 0         # library-owned 4 MiB buffer
+        bad.allreduce(0, 4, L.I64, L.SUM)
+        assert bad.lib.rsseg_ctx_set_comm(bad.h, 0, 1, L.ALLREDUCE_FN(0), None, None, 0) == 0                     # releases the communicator
+        bad.allreduce(0, 4, L.I64, L.SUM)                                                                        # no provider: the identity
+        bad.close()
         nctx.close()
         data = np.load(os.path.join(outdir, "input.npz"))
         bands = data["bands"]
