@@ -108,6 +108,45 @@ template <int NR, int NW, int MAP, int NT> double run_rw(const float *buf, float
     return bytes / (sum / reps * 1e-3) / 1e12;
 }
 
+// Plane copy with 4-byte or 16-byte accesses per lane (what bounds k5_resize: one float per lane per store, one wave
+// instruction = 256 B): grid-stride, 8192 workgroups, 16384^2 float32 in, 16384^2 float32 out (8 B/px).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_copy(const float *__restrict__ src, float *__restrict__ dst, int64_t n)
+{
+    if (VEC == 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<f4v *>(dst)[i] = reinterpret_cast<const f4v *>(src)[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    }
+}
+// the same with the 256-column strip / row walk of k5_resize: a workgroup owns 256 columns x R rows, one float per lane per row
+__global__ __launch_bounds__(256) void k_copy_strip(const float *__restrict__ src, float *__restrict__ dst, int H, int W, int gx, int R)
+{
+    const int tx = (int)(blockIdx.x % (unsigned)gx), by = (int)(blockIdx.x / (unsigned)gx);
+    const int px = tx * 256 + (int)threadIdx.x;
+    if (px >= W) return;
+    const int r1 = (by + 1) * R < H ? (by + 1) * R : H;
+#pragma unroll 8
+    for (int r = by * R; r < r1; r++) dst[(size_t)r * W + px] = src[(size_t)r * W + px];
+}
+template <int VEC> double run_copy(const float *src, float *dst, int64_t n, double *ms_out)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_copy<VEC>), dim3(8192), dim3(256), 0, 0, src, dst, n);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k_copy<VEC>), dim3(8192), dim3(256), 0, 0, src, dst, n);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / 10;
+    return (double)n * 8.0 / (ms / 10 * 1e-3) / 1e12;
+}
+
 template <int NS, int RW> double run(const float *buf, float *rw, float *sink, int64_t total_floats)
 {
     const int64_t n = (total_floats / NS) & ~(int64_t)16383;
@@ -131,6 +170,32 @@ template <int NS, int RW> double run(const float *buf, float *rw, float *sink, i
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "copy")) {
+        const int64_t n = (int64_t)16384 * 16384;
+        float *src, *dst;
+        CHECK(hipMalloc(&src, (size_t)n * 4));
+        CHECK(hipMalloc(&dst, (size_t)n * 4));
+        CHECK(hipMemset(src, 0, (size_t)n * 4));
+        CHECK(hipMemset(dst, 0, (size_t)n * 4));
+        double ms1, ms4;
+        const double r1 = run_copy<1>(src, dst, n, &ms1), r4 = run_copy<4>(src, dst, n, &ms4);
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        const int gx = 64, R = 128;
+        hipLaunchKernelGGL(k_copy_strip, dim3(gx * 128), dim3(256), 0, 0, src, dst, 16384, 16384, gx, R);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(a));
+        for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k_copy_strip, dim3(gx * 128), dim3(256), 0, 0, src, dst, 16384, 16384, gx, R);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        printf("{\n \"note\": \"copy of one 16384^2 float32 plane (4 B/px read + 4 B/px written = 2.15 GB), average of 10 launches\",\n"
+               " \"dword_per_lane_grid_stride\": {\"TBs\": %.3f, \"ms\": %.3f},\n \"16_bytes_per_lane_grid_stride\": {\"TBs\": %.3f, \"ms\": %.3f},\n"
+               " \"dword_per_lane_256_column_strips_of_128_rows\": {\"TBs\": %.3f, \"ms\": %.3f}\n}\n",
+               r1, ms1, r4, ms4, (double)n * 8.0 / (ms / 10 * 1e-3) / 1e12, ms / 10);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "write_heavy")) {
         // the config-3 raster: 16384 x 16384 px; 7 planes read, 10 float32 + 1 uint8 planes written
         const int64_t n = (int64_t)16384 * 16384;
