@@ -42,6 +42,53 @@ __global__ __launch_bounds__(256) void k_read(planes pl, float *rw, int64_t n, f
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// The k-means read pattern with another workgroup -> pixel mapping: SHAPE 1 = a workgroup reads 16 tiles of 1024 px that lie
+// RL px apart (a "strip" of a virtual RL-px-wide raster: consecutive workgroups take consecutive tiles of the same 16 virtual
+// rows), instead of 16 consecutive tiles (SHAPE 0, what the kernels do).  Pixel order is free for KMeans (exact sums).
+template <int NS, int RW, int SHAPE>
+__global__ __launch_bounds__(256) void k_read_shape(planes pl, float *rw, int64_t n, float *sink, int64_t RL)
+{
+    float acc = 0.f;
+    const int64_t gx = RL / 1024;
+    const int64_t tx = blockIdx.x % gx, by = blockIdx.x / gx;
+    for (int t = 0; t < 16; t++) {
+        const int64_t base = SHAPE == 0 ? (int64_t)blockIdx.x * 16384 + (int64_t)t * 1024 + threadIdx.x * 4
+                                        : (by * 16 + t) * RL + tx * 1024 + threadIdx.x * 4;
+        if (base + 4 > n) break;
+        float4 v[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) v[s] = *reinterpret_cast<const float4 *>(pl.p[s] + base);
+        float4 c = make_float4(0, 0, 0, 0);
+        if (RW) c = *reinterpret_cast<const float4 *>(rw + base);
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc += v[s].x + v[s].y + v[s].z + v[s].w;
+        if (RW) {
+            c.x += acc; c.y += acc; c.z += acc; c.w += acc;
+            *reinterpret_cast<float4 *>(rw + base) = c;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+template <int NS, int RW, int SHAPE> double run_shape(const float *buf, float *rw, float *sink, int64_t RL)
+{
+    const int64_t n = (int64_t)16384 * 16384;
+    planes pl;
+    for (int s = 0; s < 32; s++) pl.p[s] = buf + (int64_t)(s < NS ? s : 0) * n;
+    const unsigned grid = (unsigned)(n / 16384);
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_read_shape<NS, RW, SHAPE>), dim3(grid), dim3(256), 0, 0, pl, rw, n, sink, RL);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    const int reps = 5;
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((k_read_shape<NS, RW, SHAPE>), dim3(grid), dim3(256), 0, 0, pl, rw, n, sink, RL);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return (double)n * 4.0 * (NS + (RW ? 2 : 0)) / (ms / reps * 1e-3) / 1e12;
+}
+
 // Write-heavy pattern of the fused index + projection pass (k3_indices_project, config 3): NR float32 planes read (7 raw
 // bands = 28 B/px), NW float32 planes written (7 indices + 3 components = 40 B/px) and one uint8 plane written (1 B/px).
 // MAP 0: grid-stride over 16-byte vectors with a persistent grid (what the kernel does); MAP 1: a workgroup owns a contiguous
@@ -170,6 +217,22 @@ template <int NS, int RW> double run(const float *buf, float *rw, float *sink, i
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "shape")) {
+        const int64_t n = (int64_t)16384 * 16384;
+        float *buf, *rw, *sink;
+        CHECK(hipMalloc(&buf, (size_t)n * 4 * 15));
+        CHECK(hipMalloc(&rw, (size_t)n * 4));
+        CHECK(hipMalloc(&sink, 64));
+        CHECK(hipMemset(buf, 0, (size_t)n * 4 * 15));
+        CHECK(hipMemset(rw, 0, (size_t)n * 4));
+        printf("{\n \"note\": \"TB/s of 15 float32 planes of 16384^2 px read with 16-byte loads (16 GB), read-only / with a read-modify-write plane, against the workgroup -> pixel mapping\",\n");
+        printf(" \"chunk_of_16_consecutive_tiles\": {\"read_only\": %.3f, \"with_rw_plane\": %.3f},\n", run_shape<15, 0, 0>(buf, rw, sink, 16384), run_shape<15, 1, 0>(buf, rw, sink, 16384));
+        printf(" \"strip_row_length_4096px\": {\"read_only\": %.3f, \"with_rw_plane\": %.3f},\n", run_shape<15, 0, 1>(buf, rw, sink, 4096), run_shape<15, 1, 1>(buf, rw, sink, 4096));
+        printf(" \"strip_row_length_16384px\": {\"read_only\": %.3f, \"with_rw_plane\": %.3f},\n", run_shape<15, 0, 1>(buf, rw, sink, 16384), run_shape<15, 1, 1>(buf, rw, sink, 16384));
+        printf(" \"strip_row_length_65536px\": {\"read_only\": %.3f, \"with_rw_plane\": %.3f},\n", run_shape<15, 0, 1>(buf, rw, sink, 65536), run_shape<15, 1, 1>(buf, rw, sink, 65536));
+        printf(" \"strip_row_length_262144px\": {\"read_only\": %.3f, \"with_rw_plane\": %.3f}\n}\n", run_shape<15, 0, 1>(buf, rw, sink, 262144), run_shape<15, 1, 1>(buf, rw, sink, 262144));
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "copy")) {
         const int64_t n = (int64_t)16384 * 16384;
         float *src, *dst;
