@@ -118,8 +118,8 @@ def family_table(cfg, F, glcm_step, k, n_pca):
 
 # MFMA: the only dense contraction of the path is the 7x7 Gram / 7x3 projection of the PCA (3.5 flop/B).  It runs on the vector
 # ALUs with exact fixed-point accumulation; no MFMA instruction is issued by any kernel of the step (rocprofv3 --pmc
-# SQ_INSTS_VALU_MFMA_* = 0 for every kernel: profiles/r03_c3_pmc_sq.md), so the utilisation north_star asks to report is 0.
-MFMA_UTIL = {"value": 0.0, "note": "no MFMA instruction in the step (SQ_VALU_MFMA_BUSY_CYCLES = 0 for every kernel, profiles/r03_c3_pmc_sq.md); "
+# SQ_INSTS_VALU_MFMA_* = 0 for every kernel: profiles/r04_c3_pmc_sq.md), so the utilisation north_star asks to report is 0.
+MFMA_UTIL = {"value": 0.0, "note": "no MFMA instruction in the step (SQ_VALU_MFMA_BUSY_CYCLES = 0 for every kernel, profiles/r04_c3_pmc_sq.md); "
                                    "the PCA Gram / projection (2 x 7 x 7 flop per 28 B) run on the VALU with exact fixed-point sums — "
                                    "DESIGN.md 5: an MFMA accumulates in floating point, and even at the f64 matrix peak the 16 x 16 x 4 tiles of a 7-band Gram (137 GFLOP padded) take 1.75 ms against 1.3 ms for the kernel that exists"}
 

@@ -336,6 +336,39 @@ def test_bench_reports_a_failed_rank():
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_committed_bench_lines_carry_the_contract_fields():
+    """The JSON lines bench.py printed on the MI355X (profiles/r04_bench_*.json): every field of the driver's contract and the
+    two extra objects (roofline with live HIP-event timing of the dominant kernel and PMC traffic, cpu_baseline on a bounded
+    sample), and the arithmetic that ties them together."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_c[235]*.json")))
+    assert len(files) >= 4
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in d, (f, k)
+        assert d["metric"].startswith("Mpixel/s") and d["unit"] == "Mpixel/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+        assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+        h, w = d["config"]["raster"][:2]
+        assert abs(d["value"] - h * w / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 2e-3, f     # value = pixels / step time
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernels"):
+            assert k in r, (f, k)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and 0 < r["frac"] < 1
+        assert r["kernels_ms_per_step"] <= d["ms_per_step"] * 1.01                              # the kernels fit inside the step
+        if "c3_" in os.path.basename(f) and "rccl" not in f and "no_comm" not in f and "hard" not in f:
+            assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+            assert r["traffic"] is not None and 0.9 < r["traffic"] / r["algorithmic_bytes"] < 1.1  # measured HBM bytes = algorithmic bytes
+            c = d["cpu_baseline"]
+            assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "Mpixel/s" and "sample" in c and c["value"] > 0
+            for side in ("glcm_step7", "hard_raster", "uint8_resident", "north_star_c2_16384", "c5_16384", "pcie_inclusive"):
+                assert side in d["config"], side
+            p = d["config"]["pcie_inclusive"]
+            assert abs(p["compute_ms"] - d["ms_per_step"]) / d["ms_per_step"] < 0.05               # the serial pass times the step itself
+            assert p["double_buffered"]["value"] > p["value"] and p["uint8_bands"]["double_buffered"]["value"] > p["uint8_bands"]["value"]
+
+
 def test_bench_launcher_stops_the_other_ranks_when_one_dies():
     """One rank exits before the rendezvous, the others wait in it for ever: the launcher notices the dead child, stops the
     rest and returns non-zero within seconds (it used to block in rank 0's communicate())."""
