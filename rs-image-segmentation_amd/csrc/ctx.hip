@@ -261,7 +261,11 @@ extern "C" int rsseg_ctx_allreduce(rsseg_ctx *ctx, int64_t offset, int64_t count
         return rs_fail(ctx, RSSEG_ERR_INVALID, "allreduce: bad dtype / op / range");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int rc = ctx->allreduce(ctx->comm_user, offset, count, dtype, op);
-    if (rc != 0) return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce returned %d%s%s", rc, ctx->rccl_comm ? ": " : "", ctx->rccl_comm ? ctx->err : "");
+    if (rc != 0) {
+        char why[sizeof(ctx->err)];      // the native provider leaves RCCL's message in ctx->err: copy before formatting into it
+        snprintf(why, sizeof(why), "%s", ctx->rccl_comm ? ctx->err : "");
+        return rs_fail(ctx, RSSEG_ERR_COMM, "all-reduce returned %d%s%.400s", rc, why[0] ? ": " : "", why);
+    }
     return RSSEG_OK;
 }
 

@@ -150,11 +150,12 @@ class Context:
         if self.rank == 0:
             raw = (C.c_char * 128)()
             rc = self.lib.rsseg_rccl_unique_id(cpath, C.cast(raw, C.c_void_p))
-            if rc != 0:
-                raise RssegError(f"rsseg_rccl_unique_id failed ({rc}): {self.lib.rsseg_last_error(None).decode()}")
-            box[0] = bytes(raw.raw)
+            # a failure here travels to every rank in place of the id, so that all of them take the same decision
+            box[0] = bytes(raw.raw) if rc == 0 else f"rsseg_rccl_unique_id failed ({rc}): {self.lib.rsseg_last_error(None).decode()}"
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], bytes):
+            raise RssegError(str(box[0]))
         uid = (C.c_char * 128).from_buffer_copy(box[0])
         self._comm_buf = torch.zeros(1 << 22, dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)
