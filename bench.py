@@ -500,8 +500,10 @@ def main():
             extras["c5_16384"] = c5_extra(torch, dist, device, ctx, P, bands, H, W, n_global)
         step_qb = None
         if cfg == "c3":
-            def step_qb(dev_bands, qb):
-                lab, m, _ = P.config3(ctx, dev_bands, H, W, k, 7, args.glcm_step, 3, n_global, qb=qb)
+            def step_qb(dev_bands, qb, tex, texture_only=False):
+                if texture_only:
+                    return P.texture_planes(ctx, dev_bands[3], qb[3], H, W, 7, args.glcm_step)
+                lab, m, _ = P.config3(ctx, dev_bands, H, W, k, 7, args.glcm_step, 3, n_global, qb=qb, glcm=tex)
                 return lab, m
         extras["pcie_inclusive"] = pcie_inclusive(torch, device, ctx, bands, step, n_global, step_qb)
 
@@ -714,10 +716,11 @@ def pcie_inclusive(torch, device, ctx, bands, step, n_global, step_qb=None):
     digital numbers the TM tiles are (Context.upload_band: one byte per pixel over PCIe and in HBM, uint8 class ids back):
       serial            upload -> step -> download, nothing overlapped.  The device planes are touched and one untimed step
                         runs on them first, so `compute_ms` is the step itself (r03 had allocator growth / first touch inside)
-      pipelined         one pass, one raster: the bands cross PCIe one after the other on a copy stream and each band's
-                        order statistics (K1) are taken as soon as it has landed, while the next band is still in flight;
-                        the rest of the step needs every band's percentiles and starts when the last select is done.
-                        (Per-band, not per 2048-row stripe: a select is per band; K1 is ~0.2 ms per band of a 19 ms upload.)
+      pipelined         one pass, one raster: the bands cross PCIe one after the other on a copy stream, THE NIR BAND FIRST, and each
+                        band's order statistics (K1) are taken as soon as it has landed; the texture chain (re-normalise, quantise,
+                        GLCM, five upsamples: 18 ms) depends on the NIR band alone and runs while the other six bands are still in
+                        flight (pipeline.texture_planes); the index / PCA pass and KMeans need every band and start when the last
+                        select is done.  Same arithmetic, same labels as the serial pass (compared).
       double_buffered   a stream of rasters, what a caller with many tiles does: raster i+1 is uploaded and the labels of
                         raster i-1 are downloaded (separate copy streams, PCIe is full duplex) while raster i is computed;
                         steady-state time per raster over three rasters."""
@@ -761,31 +764,36 @@ def pcie_inclusive(torch, device, ctx, bands, step, n_global, step_qb=None):
             del labels
             main = torch.cuda.current_stream()
             up, down = torch.cuda.Stream(), torch.cuda.Stream()
-            # ---- pipelined single pass (config 3 only: needs the per-band select entry) ----
+            # ---- pipelined single pass (config 3 only) ----
             if step_qb is not None:
                 from rsseg import pipeline as P
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                evs = []
+                order = [3] + [i for i in range(len(host)) if i != 3]      # the NIR band first: the texture chain needs nothing else
+                evs = {}
                 with torch.cuda.stream(up):
-                    for h, d in zip(host, dev):
-                        d.copy_(h, non_blocking=True)
-                        e = torch.cuda.Event()
-                        e.record(up)
-                        evs.append(e)
-                qb = []
-                for d, e in zip(dev, evs):
-                    main.wait_event(e)
-                    qb.append(P.band_quantile_bundle(ctx, d, n_global))    # waits for this band only; the later bands keep flowing
+                    for i in order:
+                        dev[i].copy_(host[i], non_blocking=True)
+                        evs[i] = torch.cuda.Event()
+                        evs[i].record(up)
+                qb = [None] * len(host)
+                tex = None
+                for i in order:
+                    main.wait_event(evs[i])
+                    qb[i] = P.band_quantile_bundle(ctx, dev[i], n_global)   # waits for this band only; the later bands keep flowing
+                    if i == 3:        # quantise + GLCM + five upsamples of the NIR band run while the other six bands are in flight
+                        tex = step_qb(dev, qb, None, texture_only=True)
                 t1 = time.perf_counter()
-                labels, _ = step_qb(dev, qb)
+                labels, _ = step_qb(dev, qb, tex)
                 labels = fin(labels)
-                lab_host[0].copy_(labels, non_blocking=True)
+                lab_host[1].copy_(labels, non_blocking=True)
                 torch.cuda.synchronize()
                 t3 = time.perf_counter()
+                same = bool(torch.equal(lab_host[0], lab_host[1]))         # the serial pass's labels
                 res["pipelined"] = {"value": round(n_global / 1e6 / (t3 - t0), 2), "pass_ms": round((t3 - t0) * 1e3, 1),
-                                    "upload_and_selects_ms": round((t1 - t0) * 1e3, 1), "rest_of_step_and_download_ms": round((t3 - t1) * 1e3, 1)}
-                del labels
+                                    "upload_selects_and_texture_ms": round((t1 - t0) * 1e3, 1), "rest_of_step_and_download_ms": round((t3 - t1) * 1e3, 1),
+                                    "labels_equal_the_serial_pass": same}
+                del labels, tex
             # ---- double-buffered stream of rasters ----
             torch.cuda.synchronize()
             n_r = 4

@@ -251,7 +251,7 @@ def config2(ctx: Context, bands: Sequence, k: int = 6):
 
 @_with_minmax
 def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_window=7, glcm_step=1, n_pca=3,
-            n_global: Optional[int] = None, overlap: bool = False, qb: Optional[List[dict]] = None):
+            n_global: Optional[int] = None, overlap: bool = False, qb: Optional[List[dict]] = None, glcm: Optional[dict] = None):
     """BASELINE config 3: 7 indices + 5 GLCM properties (window 7, 4 angles) + PCA(3) -> 15 float32
     features -> KMeans(k).  One select per band serves all percentile requests (band_quantile_bundle).
     overlap=True enqueues the GLCM chain (quantise -> windows -> 5 bilinear upsamples) on a second HIP
@@ -259,7 +259,9 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     (profiles/r01_overlap_note.md): the GLCM kernel fills every CU and slows down by what the other stream
     executes (30.8 -> 44.6 ms), so the critical path does not shorten; it is off by default.
     qb: the bands' quantile bundles when the caller has them already (band_quantile_bundle per band, e.g. computed while the
-    next band was still crossing PCIe); default: one grouped select here."""
+    next band was still crossing PCIe); default: one grouped select here.
+    glcm: the five upsampled texture planes when the caller has them already (texture_planes: they depend on the NIR band
+    alone, so a caller that uploads NIR first can compute them while the other bands are still in flight)."""
     NIR = 3
     if not overlap:
         # one grouped select, then: indices (+ the normalised NIR band only), texture chain on the normalised NIR band
@@ -272,8 +274,11 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
         if fused:   # indices + PCA straight from the RAW bands: one Gram pass, one pass that writes the indices, the components and the
             # quantised texture band (the normalised NIR band itself is not needed by anything else in this configuration)
             lo2, hi2 = qb[NIR]["lo2"], qb[NIR]["hi2"]
-            idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca, quantize=(lo2, hi2, 31.0))
-            glcm, _ = glcm_features(ctx, None, H, W, 32, glcm_window, glcm_step, q=ctx.last_quantized)
+            if glcm is None:
+                idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca, quantize=(lo2, hi2, 31.0))
+                glcm, _ = glcm_features(ctx, None, H, W, 32, glcm_window, glcm_step, q=ctx.last_quantized)
+            else:
+                idx, norms, pcs, ratio, model = indices_and_pca(ctx, bands, qb, lohi, n_pca)
         else:
             idx, norms = spectral_indices(ctx, bands, lohi, want_norm=want)
             lo2, hi2 = band_percentiles(ctx, norms[NIR], (2, 98), n_global)
@@ -312,6 +317,20 @@ def config3(ctx: Context, bands: Sequence, H: int, W: int, k: int = 8, glcm_wind
     planes = [idx[n] for n in INDEX_NAMES] + [glcm[n] for n in GLCM_NAMES] + list(pcs)
     labels, meta = ctx.kmeans_fit_predict(planes, k)
     return labels, meta, planes
+
+
+@_with_minmax
+def texture_planes(ctx: Context, nir, qn: dict, H: int, W: int, glcm_window=7, glcm_step=1, levels: int = 32) -> dict:
+    """The texture chain of config 3 from the NIR band ALONE (its quantile bundle qn = band_quantile_bundle(ctx, nir)):
+    robust_normalize, the texture function's re-normalisation + quantisation (indices.py:265-268), the GLCM windows and the
+    five bilinear upsamples — the same arithmetic as the fused path of config3 (which lets the index / PCA pass write the
+    quantised band), hence the same planes bit for bit; tagged with their extrema for KMeans like config3's own."""
+    if qn["center"] is None:
+        raise ValueError("texture_planes: the band holds NaNs (use config3 without precomputed planes)")
+    x = ctx.widen_u8(nir) if Context._is_u8(nir) else nir
+    q = ctx.normalize_quantize_u8(ctx.normalize(x, float(qn["lo"]), float(qn["hi"])), float(qn["lo2"]), float(qn["hi2"]), float(levels - 1))
+    planes, _ = glcm_features(ctx, None, H, W, levels, glcm_window, glcm_step, q=q)
+    return planes
 
 
 # ------------------------------------------------------------------------------------------------

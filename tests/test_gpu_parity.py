@@ -859,6 +859,28 @@ def test_config3_pipeline_vs_oracle(ctx, oracle, H, W):
     assert np.array_equal(host(labels), want)
 
 
+@pytest.mark.parametrize("as_u8", [False, True])
+def test_texture_planes_from_the_nir_band_alone_equal_config3(ctx, oracle, as_u8):
+    """pipeline.texture_planes (the texture chain from the NIR band and its quantile bundle alone: what a caller that uploads NIR
+    first runs while the other bands are still crossing PCIe) gives config 3's five texture planes bit for bit, and config3
+    handed those planes and the per-band bundles gives the same labels, seeds and iteration count as config3 on its own."""
+    import torch
+    from rsseg import pipeline as P
+    H, W = 300, 260
+    r = oracle.synthetic_raster(H, W)
+    bands = [ctx.to_device(np.ascontiguousarray(r[i].astype(np.uint8) if as_u8 else r[i]).reshape(-1)) for i in range(7)]
+    labels, meta, planes = P.config3(ctx, bands, H, W, 8, 7, 1, 3)
+    qb = [P.band_quantile_bundle(ctx, b) for b in bands]
+    tex = P.texture_planes(ctx, bands[3], qb[3], H, W, 7, 1)
+    for i, name in enumerate(P.GLCM_NAMES):
+        assert torch.equal(tex[name].view(torch.int32), planes[7 + i].view(torch.int32)), name
+        assert getattr(tex[name], "_rsseg_minmax", None) == getattr(planes[7 + i], "_rsseg_minmax", None) is not None
+    labels2, meta2, planes2 = P.config3(ctx, bands, H, W, 8, 7, 1, 3, qb=qb, glcm=tex)
+    assert torch.equal(labels, labels2) and meta["n_iter"] == meta2["n_iter"] and np.array_equal(meta["init_indices"], meta2["init_indices"])
+    for a, b in zip(planes, planes2):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def _label_diff_report(got, want, planes64, meta):
     """How two label maps differ, judged in the product's scaled and centred space: count, the largest squared-distance gap
     between the two labels' centres at a differing pixel, and how many differing pixels have exactly their two nearest
