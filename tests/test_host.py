@@ -357,7 +357,7 @@ def test_committed_bench_lines_carry_the_contract_fields():
             assert k in r, (f, k)
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and 0 < r["frac"] < 1
         assert r["kernels_ms_per_step"] <= d["ms_per_step"] * 1.01                              # the kernels fit inside the step
-        if "c3_" in os.path.basename(f) and "rccl" not in f and "no_comm" not in f and "hard" not in f:
+        if os.path.basename(f) == "r04_bench_c3.json":      # the default line at the benchmark size (PMC passes exist for 16384^2 only)
             assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
             assert r["traffic"] is not None and 0.9 < r["traffic"] / r["algorithmic_bytes"] < 1.1  # measured HBM bytes = algorithmic bytes
             c = d["cpu_baseline"]
