@@ -1,0 +1,231 @@
+"""GPU suite, randomised differential cases: raster shapes, value distributions and parameters drawn from a seeded
+generator, the product (through the C ABI) against the CPU oracle on the same inputs.  The fixed cases of
+test_gpu_parity.py pin what the reference's own fixtures pin; these look for what nobody thought of — odd widths that are
+no multiple of any tile, rasters barely larger than a window, constant bands, heavy duplicates, cluster counts near the
+number of distinct pixels.  Integer / label outputs and IEEE-elementwise planes bit for bit, the PCA within 1e-5 of the
+float64 evaluation.  RSSEG_FUZZ_N=<n> runs n seeds per family instead of the default few (a campaign, run by hand:
+profiles/r04_fuzz_campaign.txt holds the last one)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("RSSEG_FUZZ_N", "0"))
+SEED0 = int(os.environ.get("RSSEG_FUZZ_SEED0", "0"))
+
+
+def seeds(default):
+    return list(range(SEED0, SEED0 + (N or default)))
+
+
+def dev(ctx, a, dtype=None):
+    return ctx.to_device(np.ascontiguousarray(a).reshape(-1), dtype)
+
+
+def host(t, shape=None):
+    a = t.cpu().numpy()
+    return a if shape is None else a.reshape(shape)
+
+
+def random_bands(rng, H, W, nb=7):
+    """7 float32 bands of one of the distributions the path meets: 8-bit digital numbers (the TM tiles), wider integers,
+    general floats, duplicate-heavy floats; now and then one band constant or two bands equal."""
+    kind = rng.choice(["u8", "u8_narrow", "u11", "float", "steps"])
+    yy, xx = np.mgrid[0:H, 0:W]
+    bands = []
+    for b in range(nb):
+        smooth = 60.0 * np.sin(yy / rng.uniform(3, 40) + b) * np.cos(xx / rng.uniform(3, 40) - b) + rng.uniform(60, 180)
+        noise = rng.normal(0, rng.uniform(1, 30), (H, W))
+        v = smooth + noise
+        if kind == "u8":
+            v = np.clip(np.round(v), 0, 255)
+        elif kind == "u8_narrow":
+            v = np.clip(np.round(v / 16.0), 3, 12)
+        elif kind == "u11":
+            v = np.clip(np.round(v * 8.0), 0, 2047)
+        elif kind == "steps":
+            v = np.round(v / 7.0) * 0.37 - 3.0
+        bands.append(v.astype(np.float32))
+    flip = rng.random()
+    if flip < 0.15:
+        bands[int(rng.integers(0, nb))][:] = np.float32(rng.integers(0, 200))     # a constant band: hi == lo, IQR == 0
+    elif flip < 0.3:
+        bands[int(rng.integers(4, nb))] = bands[int(rng.integers(0, 4))].copy()   # two equal bands: a singular covariance
+    return str(kind), bands
+
+
+def pca_truth64(norm_planes):
+    """float64 evaluation of perform_pca (RobustScaler, a zero inter-quartile range scaled by 1 as scikit-learn does, then PCA
+    with the sign rule of svd_flip): (components' scores [nc, N], eigenvalues)."""
+    X = np.stack([b.reshape(-1) for b in norm_planes], 1).astype(np.float32)
+    c = np.median(X, axis=0)
+    q = np.transpose([np.percentile(X[:, j], (25.0, 75.0)) for j in range(X.shape[1])])
+    sc = q[1] - q[0]
+    sc[sc < 10 * np.finfo(np.float64).eps] = 1.0
+    X = X - c
+    X = (X / sc).astype(np.float32)
+    X64 = X.astype(np.float64)
+    m = X64.mean(0)
+    C = (X64 - m).T @ (X64 - m) / (X64.shape[0] - 1)
+    w, V = np.linalg.eigh(C)
+    Vt = V[:, ::-1].T.copy()
+    Vt *= np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])[:, None]
+    return ((X64 - m) @ Vt.T).T, w[::-1]
+
+
+@pytest.mark.parametrize("seed", seeds(6))
+def test_fuzz_config3_planes_and_kmeans(ctx, oracle, seed):
+    """Random raster -> the product's config 3 (order statistics, fused index / PCA pass, texture chain at window 7 and a random
+    step, KMeans with a random k).  The 12 index / texture planes equal the oracle's bit for bit; the components are within 1e-5
+    of the float64 evaluation wherever the spectrum is well separated; KMeans is checked on the product's OWN 15 planes — the
+    oracle fed the same planes must draw the same seeds, take the same number of iterations and give the same labels."""
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(1000 + seed)
+    big = seed % 5 == 4                      # one case in five crosses tile / chunk / workgroup boundaries many times
+    H = int(rng.integers(150, 700)) if big else int(rng.integers(7, 150))
+    W = int(rng.integers(300, 1100)) if big else int(rng.integers(7, 300))
+    step = int(rng.choice([1, 1, 2, 3, 5, 7]))
+    k = int(rng.integers(2, 11))
+    kind, bands = random_bands(rng, H, W)
+    tag = dict(seed=seed, H=H, W=W, step=step, k=k, kind=kind)
+    labels, meta, planes = P.config3(ctx, [dev(ctx, b) for b in bands], H, W, k, 7, step, 3)
+    norm = [oracle.robust_normalize(b) for b in bands]
+    b, g, rd, n, s = norm[:5]
+    feats = [oracle.calculate_ndvi(n, rd), oracle.calculate_evi(n, rd, b), oracle.calculate_msavi(n, rd),
+             oracle.calculate_ndwi(g, n), oracle.calculate_mndwi(g, s), oracle.calculate_ndbi(s, n),
+             oracle.calculate_bsi(b, rd, n, s)]
+    gl, _ = oracle.calculate_glcm_features(n, 32, 7, step)
+    feats += [gl[x] for x in ("contrast", "dissimilarity", "homogeneity", "energy", "correlation")]
+    for i in range(12):
+        assert np.array_equal(host(planes[i], (H, W)), feats[i], equal_nan=True), (tag, i)
+    with np.errstate(all="ignore"):
+        truth, evals = pca_truth64(norm)
+    if np.all(np.isfinite(evals)) and np.all(np.isfinite(truth[:3])):
+        gaps = np.abs(np.diff(evals[:4]))
+        for i in range(3):
+            if min(gaps[max(i - 1, 0):i + 1].min(), evals[i]) > 5e-2:      # an isolated eigenvalue: its vector is well conditioned
+                d = float(np.abs(host(planes[12 + i], (H, W)) - truth[i].reshape(H, W)).max())
+                assert d <= 1e-5, (tag, i, d, evals[:4])
+    got_planes = [host(p) for p in planes]
+    if all(np.isfinite(p).all() for p in got_planes):
+        want, info = oracle.kmeans_fit_planes(got_planes, k)
+        assert [int(x) for x in meta["init_indices"]] == [int(x) for x in info["init_indices"]], tag
+        assert int(meta["n_iter"]) == int(info["n_iter"]) and int(meta["relocated"]) == int(info["relocated"]), tag
+        assert np.array_equal(host(labels), want), (tag, int((host(labels) != want).sum()))
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_stack19_and_forest(ctx, oracle, seed):
+    """Random raster -> the 19-feature stack (7x7 context means, texture at 21 / 21, morphology, local deviation, Sobel) against
+    the oracle's stage, then a forest fitted on random rows of that stack with random shape parameters: the product's labels
+    equal model.predict on every pixel."""
+    from sklearn.ensemble import RandomForestClassifier
+    from rsseg import pipeline as P
+    from rsseg.forest import flatten_forest
+    rng = np.random.default_rng(2000 + seed)
+    big = seed % 5 == 4
+    H = int(rng.integers(120, 500)) if big else int(rng.integers(21, 120))
+    W = int(rng.integers(200, 900)) if big else int(rng.integers(21, 200))
+    kind, bands = random_bands(rng, H, W)
+    tag = dict(seed=seed, H=H, W=W, kind=kind)
+    planes, _ = P.feature_stack19(ctx, [dev(ctx, b) for b in bands], H, W)
+    stack = P.stack19_to_host(planes, H, W)
+    with np.errstate(all="ignore"):
+        _, hier = oracle.run_feature_extraction_stage(bands)
+    ref = hier["all"]
+    assert stack.shape == ref.shape
+    for c in (0, 1, 2, 3, 4, 5, 14, 15, 16, 17, 18):          # IEEE-elementwise / integer columns
+        assert np.array_equal(stack[:, :, c], ref[:, :, c], equal_nan=True), (tag, c)
+    for c in (7, 8, 9, 10, 11, 12):                          # 7x7 means of bit-exact planes
+        assert np.allclose(stack[:, :, c], ref[:, :, c], rtol=0, atol=1e-5, equal_nan=True), (tag, c)
+    fplanes = P.stack19_forest_planes(ctx, planes)
+    X = np.stack([host(p) for p in fplanes], 1)
+    if not np.isfinite(X).all():
+        return
+    n_cls = int(rng.integers(2, 9))
+    rows = rng.choice(H * W, size=min(H * W, int(rng.integers(40, 600))), replace=False)
+    y = (rng.integers(0, n_cls, rows.size) + (X[rows, 2] > np.median(X[:, 2])) * 3) % n_cls
+    model = RandomForestClassifier(n_estimators=int(rng.integers(1, 24)), max_depth=int(rng.integers(1, 14)) if rng.random() < 0.8 else None,
+                                   random_state=int(seed), n_jobs=1).fit(X[rows], y)
+    ctx.forest_load(flatten_forest(model))
+    got = host(ctx.forest_predict(fplanes))
+    want = model.predict(X)
+    assert np.array_equal(got, want), (tag, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_rule_based(ctx, oracle, seed):
+    """Random index planes with blobs of every class -> the rule-based classifier (thresholds, elliptical open / close, hole
+    fill, 8-connected component area filter, priority painting) against the oracle: bit for bit."""
+    from modules.features import extract as E
+    rng = np.random.default_rng(3000 + seed)
+    H = int(rng.integers(5, 220))
+    W = int(rng.integers(5, 260))
+    yy, xx = np.mgrid[0:H, 0:W]
+    feats = {}
+    for name in ("ndvi", "ndwi", "mndwi", "ndbi", "bsi", "evi", "msavi"):
+        v = 0.6 * np.sin(yy / rng.uniform(4, 30) + rng.uniform(0, 6)) * np.cos(xx / rng.uniform(4, 30)) + rng.normal(0, rng.uniform(0.02, 0.3), (H, W))
+        feats[name] = v.astype(np.float32)
+    if rng.random() < 0.3:
+        del feats["mndwi"]
+    feats.update(height=H, width=W)
+    want = oracle.rule_based_classification(feats)
+    got = E.rule_based_classification(feats)
+    assert got.shape == want.shape and np.array_equal(got, want), (dict(seed=seed, H=H, W=W), int((got != want).sum()))
+
+
+@pytest.mark.parametrize("seed", seeds(3))
+def test_fuzz_row_stripes_equal_single_context(ctx, oracle, seed):
+    """Random raster, a random number of row stripes (every rank a thread with its own context and a barrier all-reduce
+    hook, test_gpu_dist._ThreadWorld), random texture step and k: labels, iteration count and the 15 planes of every stripe
+    equal the rows of the single-context result bit for bit; the 19-feature stack too when the raster is tall enough."""
+    import torch
+    from rsseg import pipeline as P
+    from rsseg.runtime import Context
+    from test_gpu_dist import _ThreadWorld
+    rng = np.random.default_rng(4000 + seed)
+    H = int(rng.integers(9, 260))
+    W = int(rng.integers(8, 200))
+    world = int(rng.integers(2, 8))
+    step = int(rng.choice([1, 1, 2, 3, 7]))
+    k = int(rng.integers(2, 9))
+    kind, bl = random_bands(rng, H, W)
+    bands = np.stack(bl)
+    with19 = H >= 42 and W >= 21             # two 21-row texture windows, one 21-column window
+    tag = dict(seed=seed, H=H, W=W, world=world, step=step, k=k, kind=kind)
+    d0 = [dev(ctx, bands[i]) for i in range(7)]
+    labels, meta, planes = P.config3(ctx, d0, H, W, k, 7, step, 3)
+    want_labels = host(labels)
+    want_planes = [host(p) for p in planes]
+    want19 = [host(p) for p in P.feature_stack19(ctx, d0, H, W)[0]] if with19 else []
+    tw = _ThreadWorld(world)
+    out = [None] * world
+
+    def rank_main(r):
+        c = Context(0, use_dist=False)
+        c.install_comm_hook(r, world, tw.hook(r))
+        r0, r1 = P.stripe_rows(H, world, r)
+        j0, j1, i0, i1 = P.glcm_halo_rows(H, r0, r1, 7, step)
+        d = [c.to_device(bands[i, r0:r1].reshape(-1)) for i in range(7)]
+        nir_ext = c.to_device(bands[3, i0:i1].reshape(-1))
+        lab, m, pl = P.config3_striped(c, d, nir_ext, H, W, r0, r1, i0, k, 7, step)
+        p19 = []
+        if with19:
+            e0, e1 = P.stack19_halo_rows(H, r0, r1)
+            p19, _ = P.stack19_striped(c, [c.to_device(bands[i, e0:e1].reshape(-1)) for i in range(7)], H, W, r0, r1, e0)
+        torch.cuda.synchronize()
+        out[r] = (r0, r1, lab.cpu().numpy(), m["n_iter"], [p.cpu().numpy() for p in pl], [p.cpu().numpy() for p in p19])
+        c.close()
+
+    tw.run(rank_main)
+    for r in range(world):
+        r0, r1, lab, n_iter, pl, p19 = out[r]
+        a, b = r0 * W, r1 * W
+        assert n_iter == meta["n_iter"], (tag, r)
+        assert np.array_equal(lab, want_labels[a:b]), (tag, r)
+        for i, p in enumerate(pl):
+            assert np.array_equal(p, want_planes[i][a:b], equal_nan=True), (tag, r, i)
+        for i, p in enumerate(p19):
+            assert np.array_equal(p, want19[i][a:b], equal_nan=True), (tag, r, i)
