@@ -51,7 +51,7 @@ def random_bands(rng, H, W, nb=7):
     flip = rng.random()
     if flip < 0.15:
         bands[int(rng.integers(0, nb))][:] = np.float32(rng.integers(0, 200))     # a constant band: hi == lo, IQR == 0
-    elif flip < 0.3:
+    elif flip < 0.3 and nb >= 7:
         bands[int(rng.integers(4, nb))] = bands[int(rng.integers(0, 4))].copy()   # two equal bands: a singular covariance
     return str(kind), bands
 
@@ -229,3 +229,41 @@ def test_fuzz_row_stripes_equal_single_context(ctx, oracle, seed):
             assert np.array_equal(p, want_planes[i][a:b], equal_nan=True), (tag, r, i)
         for i, p in enumerate(p19):
             assert np.array_equal(p, want19[i][a:b], equal_nan=True), (tag, r, i)
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_texture_dictionary_members(ctx, oracle, seed):
+    """One random band of a random shape (down to a single row or column) through the mirror's texture functions — morphology
+    at 3 / 5 / 7, local mean / variance / deviation at 1 / 3 / 5 / 7, rank entropy, Gaussian 5 / 15, DoG, Laplacian, Sobel,
+    uniform LBP — against the oracle: bit for bit, the entropies (a logarithm) within 1e-12."""
+    from modules.features import indices as I
+    rng = np.random.default_rng(5000 + seed)
+    H = int(rng.integers(1, 120))
+    W = int(rng.integers(1, 200))
+    kind, bands = random_bands(rng, H, W, nb=1)
+    band = bands[0]
+    tag = dict(seed=seed, H=H, W=W, kind=kind)
+    with np.errstate(all="ignore"):
+        want_m = oracle.calculate_morphological_features(band)
+        got_m = I.calculate_morphological_features(band)
+        for k in want_m:
+            assert np.array_equal(got_m[k], want_m[k], equal_nan=True), (tag, k)
+        ms = I.calculate_multi_scale_features(band)
+        b = oracle.robust_normalize(band)
+        u8 = oracle.to_u8(b)
+        for sc in (3, 5, 7):
+            assert np.array_equal(ms[f"std_dev_scale_{sc}"], oracle.std_dev_feature(band, sc), equal_nan=True), (tag, sc)
+            assert np.array_equal(ms[f"variance_scale_{sc}"], oracle.variance_feature(band, sc), equal_nan=True), (tag, sc)
+            assert np.array_equal(ms[f"mean_scale_{sc}"], oracle.box_mean(b, sc, "reflect101"), equal_nan=True), (tag, sc)
+        for sc in (1, 3, 5):
+            e = oracle.rank_entropy(u8, sc)
+            assert np.allclose(ms[f"entropy_scale_{sc}"], e / np.max(e), rtol=0, atol=1e-12, equal_nan=True), (tag, sc)
+        fr = I.calculate_filter_responses(band)
+        want_f = oracle.filter_responses_extra(band)
+        for k in ("gaussian_5", "gaussian_15", "dog"):
+            assert np.array_equal(fr[k], want_f[k], equal_nan=True), (tag, k)
+        assert np.array_equal(fr["sobel_mag"], oracle.sobel_mag_feature(band), equal_nan=True), tag
+        assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(band), equal_nan=True), tag
+        lbp = I.calculate_lbp_features(band)
+        o = oracle.lbp_uniform(u8, 24, 3)
+        assert np.array_equal(lbp, o / o.max(), equal_nan=True), tag
