@@ -267,3 +267,74 @@ def test_fuzz_texture_dictionary_members(ctx, oracle, seed):
         lbp = I.calculate_lbp_features(band)
         o = oracle.lbp_uniform(u8, 24, 3)
         assert np.array_equal(lbp, o / o.max(), equal_nan=True), tag
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_glcm_parameters(ctx, oracle, seed):
+    """The texture entry point on a random quantised map with random level count (2..64), window (2..23) and step (1..window+2):
+    every kernel family behind the dispatch (2 x 2 windows per thread, one window per thread, workgroup per window) against
+    the oracle's exact integer formulation, five properties bit for bit."""
+    rng = np.random.default_rng(6000 + seed)
+    levels = int(rng.choice([2, 4, 8, 16, 31, 32, 33, 48, 64]))
+    win = int(rng.choice([2, 3, 4, 5, 7, 7, 7, 9, 11, 15, 21, 23]))
+    step = int(rng.integers(1, win + 3))
+    H = int(rng.integers(win, win + 90))
+    W = int(rng.integers(win, win + 200))
+    base = rng.integers(0, levels, (H, W))
+    smooth = (np.add.outer(int(rng.integers(1, 4)) * np.arange(H), np.arange(W)) // int(rng.integers(2, 12))) % levels
+    q = np.where(rng.random((H, W)) < rng.random(), base, smooth).astype(np.uint8)
+    if rng.random() < 0.3:
+        q[: H // 2, : W // 2] = int(rng.integers(0, levels))          # constant windows: variance 0, correlation's special case
+    tag = dict(seed=seed, levels=levels, win=win, step=step, H=H, W=W)
+    want = oracle.glcm_small_maps(q, levels, win, step, mode=1)
+    got, (oh, ow) = ctx.glcm(dev(ctx, q), H, W, levels, win, step)
+    assert (oh, ow) == ((H - win) // step + 1, (W - win) // step + 1), tag
+    for g, k in zip(got, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
+        assert np.array_equal(host(g, (oh, ow)), want[k], equal_nan=True), (tag, k)
+
+
+@pytest.mark.parametrize("seed", seeds(6))
+def test_fuzz_kmeans_entry_point(ctx, oracle, seed):
+    """rsseg_kmeans_fit_predict on random matrices: 1..64 feature planes, 1..64 clusters, float32 or float64, 1..60 000 rows,
+    values continuous / on a coarse grid (ties, duplicates, clusters that run empty and are relocated) / with NaNs (the entry
+    point zeroes them as the reference does): seeds, iteration count, relocations and labels equal the oracle's bit for bit."""
+    rng = np.random.default_rng(7000 + seed)
+    F = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 19, 32, 33, 40, 64]))
+    dt = np.float64 if rng.random() < 0.3 else np.float32
+    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 60000)]))
+    k = int(min(n, rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 32, 33, 64])))
+    X = rng.random((n, F))
+    style = str(rng.choice(["continuous", "grid", "blobs", "nan"]))
+    if style == "grid":
+        X = np.round(X * int(rng.integers(1, 5))) / 4.0
+    elif style == "blobs":
+        c = rng.random((max(k, 2), F)) * 4
+        X = c[rng.integers(0, c.shape[0], n)] + rng.normal(0, 0.05, (n, F))
+    elif style == "nan":
+        X[rng.random((n, F)) < 0.02] = np.nan
+    planes = [np.ascontiguousarray(X[:, f]).astype(dt) for f in range(F)]
+    tag = dict(seed=seed, F=F, k=k, n=n, dt=dt.__name__, style=style)
+    want, info = oracle.kmeans_fit_planes(planes, k)
+    labels, meta = ctx.kmeans_fit_predict([dev(ctx, p) for p in planes], k)
+    assert [int(x) for x in meta["init_indices"]] == [int(x) for x in info["init_indices"]], tag
+    assert int(meta["n_iter"]) == int(info["n_iter"]) and int(meta["relocated"]) == int(info["relocated"]), (tag, meta["n_iter"], info["n_iter"])
+    assert np.array_equal(host(labels), want), (tag, int((host(labels) != want).sum()))
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_resize_and_order_statistics(ctx, oracle, seed):
+    """cv2.resize(INTER_LINEAR) between random shapes (up and down, 1-pixel sources) against the oracle bit for bit, and the
+    order statistics of a random plane at random ranks against np.sort."""
+    rng = np.random.default_rng(8000 + seed)
+    sh, sw = int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    dh, dw = int(rng.integers(1, 400)), int(rng.integers(1, 600))
+    src = rng.random((sh, sw)).astype(np.float32)
+    got = host(ctx.resize_bilinear(dev(ctx, src), sh, sw, dh, dw), (dh, dw))
+    assert np.array_equal(got, oracle.resize_bilinear(src, dh, dw)), dict(seed=seed, sh=sh, sw=sw, dh=dh, dw=dw)
+    n = int(rng.choice([rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 400000)]))
+    kind = str(rng.choice(["u8", "u11", "float", "neg", "dup"]))
+    a = {"u8": lambda: rng.integers(0, 256, n), "u11": lambda: rng.integers(0, 2048, n), "float": lambda: rng.standard_normal(n) * 1e3,
+         "neg": lambda: rng.integers(-50, 50, n) + rng.integers(0, 2, n) * 0.5, "dup": lambda: rng.integers(0, 3, n) * 1e-30}[kind]().astype(np.float32)
+    ranks = sorted({int(r) for r in rng.integers(0, n, min(n, 9))} | {0, n - 1})
+    vals, n_nan = ctx.order_stats(dev(ctx, a), ranks)
+    assert n_nan == 0 and np.array_equal(vals, np.sort(a)[ranks]), dict(seed=seed, n=n, kind=kind)
