@@ -459,10 +459,17 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
             const int l = left[b + g], r = right[b + g];
             if (l < 0 || r < 0 || l >= cnt || r >= cnt || newid[l] != -1 || newid[r] != -1 || feature[b + g] < 0 || feature[b + g] >= n_features)
                 return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: node %d of tree %d is malformed", g, t);
-            newid[l] = (int)order.size();
-            order.push_back(l);
-            newid[r] = (int)order.size();
-            order.push_back(r);
+            // A NaN threshold (scikit-learn >= 1.4 writes one for a split that only separates missing from non-missing values:
+            // `x <= NaN` is false, so every non-missing value goes RIGHT and a missing one where missing_go_to_left says) cannot
+            // be a threshold here: NaN marks a leaf, and `x > thr` would send everything left.  Such a node is stored with its
+            // children in the opposite order, threshold +inf and the missing flag inverted: `x > +inf` is false for every
+            // non-missing x (first slot = the right child) and a missing x takes the second slot unless the stored flag is set.
+            const bool swap = std::isnan(threshold[b + g]);
+            const int first = swap ? r : l, second = swap ? l : r;
+            newid[first] = (int)order.size();
+            order.push_back(first);
+            newid[second] = (int)order.size();
+            order.push_back(second);
         }
         if ((int)order.size() != cnt) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: tree %d has unreachable nodes", t);
         trees[t].node_off = (int)b;
@@ -500,11 +507,14 @@ extern "C" int rsseg_forest_load(rsseg_ctx *ctx, int n_trees, const int64_t *tre
                 memcpy(&nd.thr, &tb, 4);
                 nd.bits = RF_LEAF | RF_MISS | (unsigned)h;  // a leaf's "left child" is the leaf itself
             } else {
-                float f = (float)threshold[g];
-                if ((double)f > threshold[g]) f = nextafterf(f, -INFINITY);  // round toward -inf
+                const bool swap = std::isnan(threshold[g]);        // see the breadth-first numbering above
+                float f = swap ? INFINITY : (float)threshold[g];
+                if (!swap && (double)f > threshold[g]) f = nextafterf(f, -INFINITY);  // round toward -inf
                 nd.thr = f;
-                nd.bits = (unsigned)newid[left[g]] | ((unsigned)feature[g] << 26) | ((missing_go_left && missing_go_left[g]) ? RF_MISS : 0u);  // byte 3 = 4 * feature
-                if (newid[right[g]] != newid[left[g]] + 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: internal layout error");
+                const bool miss_left = missing_go_left && missing_go_left[g];
+                const int first = swap ? right[g] : left[g], second = swap ? left[g] : right[g];
+                nd.bits = (unsigned)newid[first] | ((unsigned)feature[g] << 26) | ((miss_left != swap) ? RF_MISS : 0u);  // byte 3 = 4 * feature
+                if (newid[second] != newid[first] + 1) return rs_fail(ctx, RSSEG_ERR_INVALID, "forest_load: internal layout error");
             }
         }
     }

@@ -609,7 +609,9 @@ static int pca_core(rsseg_ctx *ctx, const void *const *d_bands, bool u8, int nb,
 {
     const size_t esz = u8 ? 1 : 4;
     if (!ctx) return RSSEG_ERR_INVALID;
-    if (!d_bands || nb < 1 || nb > PCA_MAXB || n_components < 1 || n_components > nb || n_local < 0)
+    if (d_bands && nb > PCA_MAXB)   // a capacity of the kernels, not a limit of the reference: reported as UNSUPPORTED
+        return rs_fail(ctx, RSSEG_ERR_UNSUPPORTED, "pca: %d band planes, the kernels take at most %d", nb, PCA_MAXB);
+    if (!d_bands || nb < 1 || n_components < 1 || n_components > nb || n_local < 0)
         return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: bad arguments (nb=%d, n_components=%d)", nb, n_components);
     if ((center == nullptr) != (scale == nullptr)) return rs_fail(ctx, RSSEG_ERR_INVALID, "pca: center and scale must both be given or both be NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));

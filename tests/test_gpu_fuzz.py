@@ -338,3 +338,93 @@ def test_fuzz_resize_and_order_statistics(ctx, oracle, seed):
     ranks = sorted({int(r) for r in rng.integers(0, n, min(n, 9))} | {0, n - 1})
     vals, n_nan = ctx.order_stats(dev(ctx, a), ranks)
     assert n_nan == 0 and np.array_equal(vals, np.sort(a)[ranks]), dict(seed=seed, n=n, kind=kind)
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_forest_entry_point(ctx, oracle, seed):
+    """rsseg_forest_load / rsseg_forest_predict with random forests: 1..64 features, 2..40 classes with arbitrary labels, 1..30
+    trees, depth 1..unbounded (trees larger than the LDS node area take the general kernel), bootstrap on / off, training with or
+    without NaNs (scikit-learn then records where missing values go), NaN and huge values in the rows to classify, pixel counts
+    that leave ragged workgroups: labels equal model.predict on every row."""
+    from sklearn.ensemble import ExtraTreesClassifier, RandomForestClassifier
+    rng = np.random.default_rng(9000 + seed)
+    F = int(rng.choice([1, 2, 3, 5, 8, 19, 31, 32, 33, 55, 64]))
+    ncls = int(rng.choice([2, 3, 4, 5, 8, 9, 16, 17, 33, 40]))
+    ntr = int(rng.choice([30, 300, 3000, 30000]))
+    Xtr = rng.random((ntr, F)).astype(np.float32)
+    if rng.random() < 0.4:
+        Xtr = (np.round(Xtr * 8) / 8).astype(np.float32)          # thresholds that coincide with feature values
+    lab = np.sort(rng.choice(1000, ncls, replace=False)) - 500
+    ytr = lab[((Xtr[:, 0] * ncls).astype(np.int64) + (rng.random(ntr) < 0.3) * rng.integers(0, ncls, ntr)) % ncls]
+    nan_fit = rng.random() < 0.4
+    if nan_fit:
+        Xtr[rng.random((ntr, F)) < 0.03] = np.nan
+    depth = None if rng.random() < 0.25 else int(rng.integers(1, 15))
+    kw = dict(n_estimators=int(rng.integers(1, 31)), max_depth=depth, random_state=int(seed), n_jobs=4)
+    use_et = rng.random() < 0.25 and not nan_fit
+    model = (ExtraTreesClassifier(**kw) if use_et else RandomForestClassifier(bootstrap=bool(rng.random() < 0.7), **kw)).fit(Xtr, ytr)
+    n = int(rng.choice([1, 63, 64, 65, 1023, 1025, 5003, 40001]))
+    X = rng.random((n, F)).astype(np.float32)
+    if rng.random() < 0.5:
+        X = (np.round(X * 8) / 8).astype(np.float32)
+    if rng.random() < 0.6:
+        X[rng.random((n, F)) < 0.02] = np.nan
+    if rng.random() < 0.3:
+        X[rng.random((n, F)) < 0.01] = np.float32(3.0e38)
+        X[rng.random((n, F)) < 0.01] = np.float32(-3.0e38)
+    tag = dict(seed=seed, F=F, classes=len(model.classes_), trees=kw["n_estimators"], depth=depth, n=n, nan_fit=nan_fit, extra_trees=use_et,
+               nodes=max(e.tree_.node_count for e in model.estimators_))
+    model.set_params(n_jobs=1)      # with several jobs scikit-learn adds the trees' votes in the order the threads finish: near-ties flip
+    want = model.predict(X)
+    ctx.forest_load(oracle.flatten_forest(model))
+    got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(F)]))
+    assert np.array_equal(got, want), (tag, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_pca_entry_point(ctx, oracle, seed):
+    """perform_pca through the product on 2..12 random planes of a random size, with and without the RobustScaler, a random number
+    of components: scores within 1e-5 of the float64 evaluation for every well-separated eigenvalue, explained-variance ratios
+    within 1e-6, and the two paths (normalised planes in memory / raw planes normalised inside the kernels) bit-identical."""
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(9500 + seed)
+    nb = int(rng.integers(2, 11))
+    H, W = int(rng.integers(3, 200)), int(rng.integers(3, 300))
+    kind, bands = random_bands(rng, H, W, nb=nb)
+    robust = bool(rng.random() < 0.75)
+    nc = None if rng.random() < 0.3 else int(rng.integers(1, nb + 1))
+    if H * W <= nb:
+        return
+    norm = [oracle.robust_normalize(b) for b in bands]
+    tag = dict(seed=seed, nb=nb, H=H, W=W, kind=kind, robust=robust, nc=nc)
+    if nb > 8:       # the kernels take at most 8 band planes (the TM scenes have 7): refused as a capacity, by name
+        from rsseg.runtime import RssegUnsupported
+        with pytest.raises(RssegUnsupported, match="at most 8"):
+            P.pca(ctx, [dev(ctx, b) for b in norm], nc, robust)
+        return
+    pcs, ratio, model = P.pca(ctx, [dev(ctx, b) for b in norm], nc, robust)
+    X = np.stack([b.reshape(-1) for b in norm], 1).astype(np.float32)
+    if robust:
+        c = np.median(X, axis=0)
+        q = np.transpose([np.percentile(X[:, j], (25.0, 75.0)) for j in range(nb)])
+        sc = q[1] - q[0]
+        sc[sc < 10 * np.finfo(np.float64).eps] = 1.0
+        X = ((X - c) / sc).astype(np.float32)
+    X64 = X.astype(np.float64)
+    m = X64.mean(0)
+    C = (X64 - m).T @ (X64 - m) / (X64.shape[0] - 1)
+    w, V = np.linalg.eigh(C)
+    w, Vt = w[::-1], V[:, ::-1].T.copy()
+    Vt *= np.sign(Vt[np.arange(nb), np.argmax(np.abs(Vt), axis=1)])[:, None]
+    truth = ((X64 - m) @ Vt.T).T
+    k = nb if nc is None else nc
+    assert len(pcs) == k, tag
+    if w.sum() > 0:
+        assert np.allclose(np.asarray(ratio, np.float64), (w / w.sum())[:k], rtol=0, atol=2e-6), (tag, ratio, (w / w.sum())[:k])
+    scale = max(1.0, float(np.abs(truth).max()))
+    for i in range(k):
+        lo = w[i] - w[i + 1] if i + 1 < nb else w[i]
+        hi = w[i - 1] - w[i] if i > 0 else np.inf
+        if min(lo, hi) > 5e-2 * max(w[0], 1e-30):
+            d = float(np.abs(host(pcs[i]) - truth[i]).max())
+            assert d <= 1e-5 * scale, (tag, i, d, w[:4])

@@ -730,6 +730,34 @@ def test_forest_six_classes_and_nan_rows_vs_sklearn(ctx, oracle):
     assert len(f["classes"]) == 6 and np.array_equal(got, want)
 
 
+def test_forest_nan_threshold_splits_vs_sklearn(ctx, oracle):
+    """Forests fitted on data WITH missing values: scikit-learn (>= 1.4) may then choose a split that only separates missing from
+    non-missing values and records it with threshold NaN — `x <= NaN` is false, every non-missing value goes right, a missing one
+    where missing_go_to_left says.  (Found by tests/test_gpu_fuzz.py in round 4: the loader used to store the NaN as it was, and
+    NaN thresholds mark leaves in the walk.)  Rows with and without NaNs, both kernels' class widths, against model.predict and
+    the oracle."""
+    from sklearn.ensemble import RandomForestClassifier
+    found = 0
+    for seed, ncls, F in ((0, 3, 5), (1, 13, 19), (2, 8, 55), (3, 9, 19), (4, 4, 3), (5, 20, 7)):
+        rng = np.random.default_rng(500 + seed)
+        Xtr = rng.random((30, F)).astype(np.float32)
+        Xtr[rng.random((30, F)) < 0.08] = np.nan
+        ytr = rng.integers(0, ncls, 30) * 7 - 20
+        model = RandomForestClassifier(n_estimators=25, max_depth=6, random_state=seed, n_jobs=1).fit(Xtr, ytr)
+        n_nan_thr = sum(int(np.isnan(e.tree_.threshold[e.tree_.children_left >= 0]).sum()) for e in model.estimators_)
+        found += n_nan_thr
+        f = oracle.flatten_forest(model)
+        ctx.forest_load(f)
+        for with_nan in (False, True):
+            X = rng.random((5003, F)).astype(np.float32)
+            if with_nan:
+                X[rng.random((5003, F)) < 0.05] = np.nan
+            got = host(ctx.forest_predict([dev(ctx, X[:, i]) for i in range(F)]))
+            assert np.array_equal(got, model.predict(X)), (seed, with_nan, n_nan_thr)
+            assert np.array_equal(got, oracle.rf_predict_planes(f, [np.ascontiguousarray(X[:, i]) for i in range(F)])), (seed, with_nan)
+    assert found > 0          # the case is really exercised
+
+
 def test_forest_degenerate_shapes_vs_sklearn(ctx, oracle):
     """A forest whose trees are single leaves (one class in the training set), a single tree, a single stump, one pixel
     and an empty raster: the walk has nothing to walk, the vote table has one row per leaf."""

@@ -338,3 +338,24 @@ def test_pin_report_is_committed(golden_dir):
     assert rep["class_map_agreement"] >= 0.999
     assert rep["rf_mismatch"] == 0 and rep["robust_normalize_bitexact"]
     assert all(rep["indices_bitexact"].values())
+
+
+def test_forest_walk_with_nan_threshold_splits_equals_sklearn(oracle):
+    """A forest fitted on data with missing values can hold splits whose threshold is NaN (scikit-learn >= 1.4: the split only
+    separates missing from non-missing values; `x <= NaN` is false, so non-missing values go right).  The oracle's walk follows
+    Tree._apply_dense literally and must agree with model.predict on rows with and without NaNs."""
+    from sklearn.ensemble import RandomForestClassifier
+    found = 0
+    for seed, ncls, F in ((0, 3, 5), (1, 13, 19), (2, 8, 55), (3, 9, 19), (4, 4, 3), (5, 20, 7)):
+        rng = np.random.default_rng(500 + seed)
+        Xtr = rng.random((30, F)).astype(np.float32)
+        Xtr[rng.random((30, F)) < 0.08] = np.nan
+        ytr = rng.integers(0, ncls, 30) * 7 - 20
+        model = RandomForestClassifier(n_estimators=25, max_depth=6, random_state=seed, n_jobs=1).fit(Xtr, ytr)
+        found += sum(int(np.isnan(e.tree_.threshold[e.tree_.children_left >= 0]).sum()) for e in model.estimators_)
+        f = oracle.flatten_forest(model)
+        X = rng.random((2000, F)).astype(np.float32)
+        X[rng.random((2000, F)) < 0.05] = np.nan
+        X[:500] = np.nan_to_num(X[:500], nan=0.5)
+        assert np.array_equal(oracle.rf_predict_planes(f, [np.ascontiguousarray(X[:, i]) for i in range(F)]), model.predict(X)), seed
+    assert found > 0
