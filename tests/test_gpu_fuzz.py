@@ -425,6 +425,42 @@ def test_fuzz_pca_entry_point(ctx, oracle, seed):
     for i in range(k):
         lo = w[i] - w[i + 1] if i + 1 < nb else w[i]
         hi = w[i - 1] - w[i] if i > 0 else np.inf
-        if min(lo, hi) > 5e-2 * max(w[0], 1e-30):
+        rel_gap = min(lo, hi) / max(w[0], 1e-30)
+        if rel_gap > 5e-2:
+            # an eigenvector's sensitivity to float32 rounding of the covariance grows with 1 / gap: 1e-5 for gaps of a fifth of the
+            # spectrum and more (the bar of DESIGN 4), proportionally more below (seed 1059: gap 0.146 of w[0], 1.05e-5)
             d = float(np.abs(host(pcs[i]) - truth[i]).max())
-            assert d <= 1e-5 * scale, (tag, i, d, w[:4])
+            assert d <= 1e-5 * scale * max(1.0, 0.2 / rel_gap), (tag, i, d, w[:4])
+
+
+@pytest.mark.parametrize("seed", seeds(4))
+def test_fuzz_threshold_and_post_processing(ctx, oracle, seed):
+    """threshold_segmentation (fixed threshold above / below, float32 and float64 planes, NaNs, Otsu incl. planes without
+    contrast) and advanced_post_processing (random mask density, min_area, elliptical element of an odd size 1..31, an even size
+    -> hole fill) of the mirror against the oracle's restatements of cv2 / scipy.ndimage: bit for bit."""
+    from modules.features import extract as E
+    rng = np.random.default_rng(9800 + seed)
+    H, W = int(rng.integers(1, 160)), int(rng.integers(1, 220))
+    yy, xx = np.mgrid[0:H, 0:W]
+    plane = (np.sin(yy / rng.uniform(2, 25)) * np.cos(xx / rng.uniform(2, 25)) + rng.normal(0, rng.uniform(0.01, 0.5), (H, W)))
+    plane = plane.astype(np.float32 if rng.random() < 0.6 else np.float64)
+    if rng.random() < 0.3:
+        plane[rng.random((H, W)) < 0.05] = np.nan
+    if rng.random() < 0.1:
+        plane[:] = plane.flat[0] if np.isfinite(plane.flat[0]) else 0.25       # no contrast
+    tag = dict(seed=seed, H=H, W=W, dtype=str(plane.dtype))
+    thr = float(rng.uniform(-0.8, 0.8))
+    for above in (True, False):
+        assert np.array_equal(E.threshold_segmentation(plane, thr, above), oracle.threshold_segmentation(plane, thr, above)), (tag, thr, above)
+    with np.errstate(all="ignore"):
+        want_o = oracle.threshold_segmentation(plane, None, True, otsu=True)
+    assert np.array_equal(E.threshold_segmentation(plane, None, True, otsu=True), want_o), (tag, "otsu")
+    mask = (rng.random((H, W)) < rng.uniform(0.1, 0.9)).astype(np.uint8)
+    if H > 12 and W > 12:
+        mask[3:H // 2, 3:W // 2] = 1
+        mask[5:H // 2 - 2, 5:W // 2 - 2] = rng.random((max(H // 2 - 7, 0), max(W // 2 - 7, 0))) < 0.7      # holes inside a block
+    k = int(rng.choice([0, 1, 2, 3, 3, 4, 5, 5, 7, 9, 11, 15, 21, 31]))
+    min_area = int(rng.choice([0, 1, 2, 5, 30, 200, 100000]))
+    got = E.advanced_post_processing(mask, min_area, k)
+    want = oracle.advanced_post_processing(mask, min_area, k)
+    assert np.array_equal(got, want), (tag, k, min_area, int((got != want).sum()))
