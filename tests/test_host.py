@@ -488,3 +488,42 @@ def test_save_classification_as_geotiff_follows_the_reference(tmp_path, capsys):
     neg = np.full((260, 300), -3, np.int64)
     save_classification_as_geotiff(neg, meta, p)
     assert read_tiff(p).dtype == np.int32
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tiff_and_lzw_randomised_round_trips(tmp_path, seed):
+    """Random shapes (down to 1 x 1, widths and heights around the 256-pixel tile), dtypes, band counts, strip / tile / LZW /
+    BigTIFF forms: what write_tiff writes, read_tiff reads back bit for bit, and for one-band 8-bit / float32 rasters Pillow's
+    libtiff reads the same values; the LZW codec round-trips random byte strings of random alphabets and run lengths (table
+    resets, the 4094-entry boundary)."""
+    from PIL import Image
+    from rsseg.tiff import lzw_decode, lzw_encode, read_tiff, write_tiff
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(6):
+        n = int(rng.choice([0, 1, 2, 255, 256, 4093, 4094, 4095, 4096, 50000, 300000]))
+        alphabet = int(rng.choice([1, 2, 3, 16, 256]))
+        data = rng.integers(0, alphabet, n, dtype=np.uint8)
+        if rng.random() < 0.5 and n > 10:                # long runs
+            data = np.repeat(data[: max(n // 50, 1)], 50)[:n]
+        data = bytes(data)
+        assert lzw_decode(lzw_encode(data), len(data)) == data, (seed, n, alphabet)
+    for _ in range(5):
+        H = int(rng.choice([1, 2, 7, 255, 256, 257, 300, 513]))
+        W = int(rng.choice([1, 3, 255, 256, 257, 400, 515]))
+        B = int(rng.choice([1, 1, 2, 3, 7, 19]))
+        dt = rng.choice(["u1", "u2", "i2", "i4", "f4", "f8"])
+        if dt[0] == "f":
+            a = rng.random((B, H, W)).astype(dt)
+        else:
+            hi = {"u1": 256, "u2": 65536, "i2": 32768, "i4": 2 ** 31}[str(dt)]
+            a = rng.integers(-hi if dt[0] == "i" else 0, hi, (B, H, W)).astype(dt)
+        if rng.random() < 0.4:
+            a[:, : H // 2] = a.flat[0]                    # compressible halves
+        kw = dict(compress=rng.choice([None, "lzw"]), tiled=[None, True, False][int(rng.integers(0, 3))], bigtiff=[None, True][int(rng.integers(0, 2))])
+        p = str(tmp_path / "r.tif")
+        write_tiff(p, a if B > 1 or rng.random() < 0.5 else a[0], **kw)
+        back = read_tiff(p)
+        assert back.dtype == a.dtype and np.array_equal(back, a), (seed, H, W, B, dt, kw)
+        if B == 1 and dt in ("u1", "f4") and not kw["bigtiff"]:
+            with Image.open(p) as im:
+                assert np.array_equal(np.asarray(im), a[0]), (seed, H, W, dt, kw)
