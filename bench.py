@@ -565,7 +565,7 @@ def main():
             roof["dominant_by_time"] = dom["name"]
             # north_star: "MFMA used only for the PCA covariance/projection GEMM, with rocprof-reported ... MFMA utilisation"
             roof["mfma_util"] = MFMA_UTIL["value"]
-            roof["mfma_note"] = MFMA_UTIL["note"]
+            roof["mfma_note"] = MFMA_UTIL["note"].replace("r04_c3_pmc_sq.md", "r04_c5_pmc_sq.md") if cfg == "c5" else MFMA_UTIL["note"]
             roof["kernels"] = kernels
             roof["kernels_ms_per_step"] = round(sum(e["ms_per_step"] for e in kernels), 2)
         cpu = None
