@@ -66,7 +66,7 @@ def robust_normalize(band: np.ndarray, lower_percentile=2, upper_percentile=98) 
     NumPy-2 promotion, `+ 1e-10` is absorbed: everything stays float32."""
     lo = np.percentile(band, lower_percentile)
     hi = np.percentile(band, upper_percentile)
-    clipped = np.minimum(np.maximum(band, lo), hi)
+    clipped = np.clip(band, lo, hi)      # the reference's call: keeps a -0.0 that equals the lower bound (np.maximum would not)
     return (clipped - lo) / (hi - lo + 1e-10)
 
 

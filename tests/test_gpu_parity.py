@@ -1407,6 +1407,40 @@ def test_config3_on_uint8_bands_equals_float32_bands(ctx, oracle):
         assert torch.equal(a, b) or torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def bits_equal(a, b):
+    """Equal bit for bit (so that -0.0 != +0.0), NaNs at the same places (their payloads are not compared)."""
+    a, b = np.ascontiguousarray(a, np.float32).reshape(-1), np.ascontiguousarray(b, np.float32).reshape(-1)
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.int32)[~na], b.view(np.int32)[~na]))
+
+
+def test_signed_zeros_follow_numpy(ctx, oracle):
+    """Bands that hold -0.0 (np.round of a small negative number; a float raster can carry them, 8-bit digital numbers cannot):
+    np.clip keeps a -0.0 that equals the lower bound, so robust_normalize returns -0.0 there and the ratio indices carry the sign
+    on (found by tests/test_gpu_fuzz.py in round 4 — the oracle's np.maximum / np.minimum form lost it; the kernels had it right).
+    Normalised planes and the seven indices of the product, separate kernels and the fused pass, against the oracle BIT for bit."""
+    from rsseg import pipeline as P
+    rng = np.random.default_rng(41)
+    H, W = 60, 77
+    bands = [np.clip(np.round(rng.normal(1.0, 2.0, (H, W))), 0, 6).astype(np.float32) for _ in range(7)]    # -0.0 where round(-0.3) landed
+    assert sum(int(np.signbit(b[b == 0]).sum()) for b in bands) > 50
+    norm = [oracle.robust_normalize(b) for b in bands]
+    assert any(np.signbit(n[n == 0]).any() for n in norm)
+    d = [dev(ctx, b) for b in bands]
+    lohi = P.band_lohi(ctx, d, H * W)
+    for i in range(7):
+        assert bits_equal(host(ctx.normalize(d[i], float(lohi[i, 0]), float(lohi[i, 1]))), norm[i]), i
+    b, g, r, n, s = norm[:5]
+    want = [oracle.calculate_ndvi(n, r), oracle.calculate_evi(n, r, b), oracle.calculate_msavi(n, r), oracle.calculate_ndwi(g, n),
+            oracle.calculate_mndwi(g, s), oracle.calculate_ndbi(s, n), oracle.calculate_bsi(b, r, n, s)]
+    idx, _ = P.spectral_indices(ctx, d, lohi)
+    for name, w in zip(P.INDEX_NAMES, want):
+        assert bits_equal(host(idx[name]), w), name
+    _, _, planes = P.config3(ctx, d, H, W, 4, 7, 1, 3)          # the fused index / PCA pass
+    for i, w in enumerate(want):
+        assert bits_equal(host(planes[i]), w), ("fused", i)
+
+
 def test_normalise_division_is_the_ieee_quotient(ctx):
     """robust_normalize's (clip(x) - lo) / (hi - lo + 1e-10) on the device: bit-equal to NumPy's float32 quotient for
     ordinary, tiny, huge and degenerate ranges, and for numerators down to the denormals (no flush to zero, no
