@@ -58,10 +58,15 @@ def random_bands(rng, H, W, nb=7, neg_zero=True):
 
 
 def bits_equal(a, b):
-    """Equal bit for bit (-0.0 != +0.0), NaNs at the same places."""
-    a, b = np.ascontiguousarray(a, np.float32).reshape(-1), np.ascontiguousarray(b, np.float32).reshape(-1)
+    """Equal bit for bit (-0.0 != +0.0), same dtype, NaNs at the same places (payloads not compared)."""
+    a, b = np.ascontiguousarray(a).reshape(-1), np.ascontiguousarray(b).reshape(-1)
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if a.dtype.kind != "f":
+        return bool(np.array_equal(a, b))
+    it = {4: np.int32, 8: np.int64}[a.dtype.itemsize]
     na, nb = np.isnan(a), np.isnan(b)
-    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.int32)[~na], b.view(np.int32)[~na]))
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(it)[~na], b.view(it)[~na]))
 
 
 def pca_truth64(norm_planes):
@@ -145,7 +150,7 @@ def test_fuzz_stack19_and_forest(ctx, oracle, seed):
     ref = hier["all"]
     assert stack.shape == ref.shape
     for c in (0, 1, 2, 3, 4, 5, 14, 15, 16, 17, 18):          # IEEE-elementwise / integer columns
-        assert np.array_equal(stack[:, :, c], ref[:, :, c], equal_nan=True), (tag, c)
+        assert bits_equal(stack[:, :, c], ref[:, :, c]), (tag, c)
     for c in (7, 8, 9, 10, 11, 12):                          # 7x7 means of bit-exact planes
         assert np.allclose(stack[:, :, c], ref[:, :, c], rtol=0, atol=1e-5, equal_nan=True), (tag, c)
     fplanes = P.stack19_forest_planes(ctx, planes)
@@ -255,26 +260,26 @@ def test_fuzz_texture_dictionary_members(ctx, oracle, seed):
         want_m = oracle.calculate_morphological_features(band)
         got_m = I.calculate_morphological_features(band)
         for k in want_m:
-            assert np.array_equal(got_m[k], want_m[k], equal_nan=True), (tag, k)
+            assert bits_equal(got_m[k], want_m[k]), (tag, k)
         ms = I.calculate_multi_scale_features(band)
         b = oracle.robust_normalize(band)
         u8 = oracle.to_u8(b)
         for sc in (3, 5, 7):
-            assert np.array_equal(ms[f"std_dev_scale_{sc}"], oracle.std_dev_feature(band, sc), equal_nan=True), (tag, sc)
-            assert np.array_equal(ms[f"variance_scale_{sc}"], oracle.variance_feature(band, sc), equal_nan=True), (tag, sc)
-            assert np.array_equal(ms[f"mean_scale_{sc}"], oracle.box_mean(b, sc, "reflect101"), equal_nan=True), (tag, sc)
+            assert bits_equal(ms[f"std_dev_scale_{sc}"], oracle.std_dev_feature(band, sc)), (tag, sc)
+            assert bits_equal(ms[f"variance_scale_{sc}"], oracle.variance_feature(band, sc)), (tag, sc)
+            assert bits_equal(ms[f"mean_scale_{sc}"], oracle.box_mean(b, sc, "reflect101")), (tag, sc)
         for sc in (1, 3, 5):
             e = oracle.rank_entropy(u8, sc)
             assert np.allclose(ms[f"entropy_scale_{sc}"], e / np.max(e), rtol=0, atol=1e-12, equal_nan=True), (tag, sc)
         fr = I.calculate_filter_responses(band)
         want_f = oracle.filter_responses_extra(band)
         for k in ("gaussian_5", "gaussian_15", "dog"):
-            assert np.array_equal(fr[k], want_f[k], equal_nan=True), (tag, k)
-        assert np.array_equal(fr["sobel_mag"], oracle.sobel_mag_feature(band), equal_nan=True), tag
-        assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(band), equal_nan=True), tag
+            assert bits_equal(fr[k], want_f[k]), (tag, k)
+        assert bits_equal(fr["sobel_mag"], oracle.sobel_mag_feature(band)), tag
+        assert bits_equal(fr["laplacian"], oracle.laplacian_feature(band)), tag
         lbp = I.calculate_lbp_features(band)
         o = oracle.lbp_uniform(u8, 24, 3)
-        assert np.array_equal(lbp, o / o.max(), equal_nan=True), tag
+        assert bits_equal(lbp, o / o.max()), tag
 
 
 @pytest.mark.parametrize("seed", seeds(4))
@@ -298,7 +303,7 @@ def test_fuzz_glcm_parameters(ctx, oracle, seed):
     got, (oh, ow) = ctx.glcm(dev(ctx, q), H, W, levels, win, step)
     assert (oh, ow) == ((H - win) // step + 1, (W - win) // step + 1), tag
     for g, k in zip(got, ["contrast", "dissimilarity", "homogeneity", "energy", "correlation"]):
-        assert np.array_equal(host(g, (oh, ow)), want[k], equal_nan=True), (tag, k)
+        assert bits_equal(host(g, (oh, ow)), want[k]), (tag, k)
 
 
 @pytest.mark.parametrize("seed", seeds(6))
@@ -338,7 +343,7 @@ def test_fuzz_resize_and_order_statistics(ctx, oracle, seed):
     dh, dw = int(rng.integers(1, 400)), int(rng.integers(1, 600))
     src = rng.random((sh, sw)).astype(np.float32)
     got = host(ctx.resize_bilinear(dev(ctx, src), sh, sw, dh, dw), (dh, dw))
-    assert np.array_equal(got, oracle.resize_bilinear(src, dh, dw)), dict(seed=seed, sh=sh, sw=sw, dh=dh, dw=dw)
+    assert bits_equal(got, oracle.resize_bilinear(src, dh, dw)), dict(seed=seed, sh=sh, sw=sw, dh=dh, dw=dw)
     n = int(rng.choice([rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 400000)]))
     kind = str(rng.choice(["u8", "u11", "float", "neg", "dup"]))
     a = {"u8": lambda: rng.integers(0, 256, n), "u11": lambda: rng.integers(0, 2048, n), "float": lambda: rng.standard_normal(n) * 1e3,
