@@ -30,6 +30,13 @@ def _dev(a):
     a = np.asarray(a)
     if a.ndim != 2:
         raise ValueError("expected a 2-D band array")
+    if a.dtype.kind == "f" and a.dtype.itemsize > 4:
+        # the reference would carry a float64 band through in float64 (NumPy promotion); the kernels of these functions compute
+        # in float32 — the dtype scripts/2_feature_extraction.py:156 gives every band.  Narrowing silently would return other
+        # values under the reference's name, so it is refused by name instead.
+        from rsseg.runtime import RssegUnsupported
+        raise RssegUnsupported(f"{a.dtype} band: these functions compute in float32 (what scripts/2 passes: src.read(i).astype(np.float32)); "
+                               "cast the band with .astype(np.float32) to get the float32 result")
     return _ctx().to_device(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)), a.shape
 
 

@@ -37,6 +37,20 @@ def test_indices_module_matches_reference_functions(ctx, crop):
     assert I.calculate_evi(n, r, b, L=2).shape == n.shape   # any coefficients (test_evi_coefficients_... checks the values)
 
 
+def test_float64_bands_are_refused_by_name(ctx, crop):
+    """NumPy would carry a float64 band through the reference's band-level functions in float64; the kernels behind the mirror
+    compute in float32 (the dtype scripts/2:156 gives every band).  Narrowing silently would return different values under the
+    reference's name: the mirror refuses the dtype instead, and says what to do."""
+    from modules.features import indices as I
+    from rsseg.runtime import RssegUnsupported
+    b64 = crop["bands"][3].astype(np.float64)
+    for call in (lambda: I.robust_normalize(b64), lambda: I.calculate_ndvi(b64, b64), lambda: I.perform_pca([b64, b64]),
+                 lambda: I.calculate_glcm_features(b64), lambda: I.calculate_filter_responses(b64)):
+        with pytest.raises(RssegUnsupported, match="astype"):
+            call()
+    assert I.robust_normalize(b64.astype(np.float32)).dtype == np.float32
+
+
 def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
     """calculate_morphological_features / calculate_multi_scale_features / calculate_filter_responses of the mirror:
     member names, dtypes and values of the members that are produced (reference indices.py:401-482, 519-562)."""
