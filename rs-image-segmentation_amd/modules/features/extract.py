@@ -233,6 +233,14 @@ def _f32(features_dict, key, shape=None):
     v = features_dict.get(key)
     if v is None or (shape is not None and np.asarray(v).shape != shape):
         return None
+    v = np.asarray(v)
+    if v.dtype.kind == "f" and v.dtype.itemsize > 4:
+        # NumPy compares a float64 plane with the rule's thresholds in float64 (0.2 is not float32(0.2)); these functions compare in
+        # float32, the dtype of the index planes the feature stage writes.  Refused by name rather than narrowed silently;
+        # threshold_segmentation itself takes float64 planes (its own float64 kernel).
+        from rsseg.runtime import RssegUnsupported
+        raise RssegUnsupported(f"feature '{key}' is {v.dtype}: the rule functions compare float32 planes (what the feature stage writes); "
+                               "cast with .astype(np.float32), or call threshold_segmentation, which compares float64 planes in float64")
     return _ctx().to_device(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
 
 

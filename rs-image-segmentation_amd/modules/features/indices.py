@@ -229,6 +229,11 @@ def add_spatial_context(features_array, window_size=7):
     if features_array.ndim != 3:
         raise ValueError("add_spatial_context expects an (H, W, C) array")
     h, w, c = features_array.shape
+    if features_array.dtype.kind == "f" and features_array.dtype.itemsize > 4:
+        # cv2.boxFilter(feature, -1, ...) answers in the depth of its input: a float64 stack would be averaged and returned in float64
+        from rsseg.runtime import RssegUnsupported
+        raise RssegUnsupported(f"{features_array.dtype} stack: the context mean is computed on float32 planes (prepare_level_1_features stacks "
+                               "float32 planes); cast with .astype(np.float32)")
     ctx = _ctx()
     context = np.zeros((h, w, c))
     for i in range(c):

@@ -49,6 +49,13 @@ def test_float64_bands_are_refused_by_name(ctx, crop):
         with pytest.raises(RssegUnsupported, match="astype"):
             call()
     assert I.robust_normalize(b64.astype(np.float32)).dtype == np.float32
+    with pytest.raises(RssegUnsupported, match="astype"):
+        I.add_spatial_context(np.stack([b64, b64], axis=-1))
+    from modules.features import extract as E
+    f64 = dict(ndvi=b64, ndbi=b64, ndwi=b64, height=96, width=96)
+    with pytest.raises(RssegUnsupported, match="threshold_segmentation"):
+        E.rule_based_classification(f64)
+    assert E.threshold_segmentation(b64, 0.2).dtype == np.uint8            # the float64 comparison exists where the reference has it
 
 
 def test_texture_feature_dicts_match_oracle(ctx, crop, oracle):
@@ -89,8 +96,8 @@ def test_window_operators_on_rasters_smaller_than_their_windows(ctx, oracle, sha
     fr = I.calculate_filter_responses(band)
     assert np.array_equal(fr["sobel_mag"], oracle.sobel_mag_feature(band), equal_nan=True), shape
     assert np.array_equal(fr["laplacian"], oracle.laplacian_feature(band), equal_nan=True), shape
-    ctxm = I.add_spatial_context(np.stack([band.astype(np.float64)] * 2, axis=-1), 7)
-    assert np.array_equal(ctxm, oracle.add_spatial_context(np.stack([band.astype(np.float64)] * 2, axis=-1), 7)), shape
+    ctxm = I.add_spatial_context(np.stack([band] * 2, axis=-1), 7)
+    assert ctxm.dtype == np.float64 and np.array_equal(ctxm, oracle.add_spatial_context(np.stack([band] * 2, axis=-1), 7)), shape
 
 
 def test_stage_takes_uint8_bands_like_float32_bands(ctx, crop):
