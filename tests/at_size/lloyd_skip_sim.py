@@ -4,9 +4,9 @@ d(x, nearest centre) at its last evaluation against the cumulative drift 2 * sum
 On the reference's bundled scene (600 x 600, the 7 spectral indices, k = 6 / 8: 47 / 51 iterations) this prints, per
 iteration, the fraction of pixels and of 32-pixel groups (one 128-byte line of a float32 plane: the granularity at which
 skipping saves HBM traffic) that must be re-evaluated, the fraction that really changes, and the check that no skipped
-pixel ever changes (viol = 0).   python3 profiles/lloyd_skip_sim.py > profiles/r03_lloyd_skip_sim.txt"""
+pixel ever changes (viol = 0).   python3 tests/at_size/lloyd_skip_sim.py > profiles/r03_lloyd_skip_sim.txt"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rs-image-segmentation_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rs-image-segmentation_amd"))
 import numpy as np
 from oracle import ref_np as O
 

@@ -5,8 +5,8 @@ plane-by-plane equality, the PCA deviations and the label agreement (A: literal 
 C: CPU path fed the float64-exact components; D: oracle KMeans on the PRODUCT's own 15 planes — the KMeans kernels alone),
 with the near-tie proof for differing labels and, where k-means++ drew another seed (D^2 sampling turns a 1e-7 perturbation of
 three planes into another pixel once the raster has tens of millions of them), the agreement after the best relabelling.
-Usage (GPU box; the oracle is the CHECKER here): python profiles/r04_parity_at_size.py 4096 > gpurun_out/r04/parity_4096.json
-       python profiles/r04_parity_at_size.py 16384 kmeans-only > ...   D alone, on the raster bench.py times (generated on the device):
+Usage (GPU box; the oracle is the CHECKER here): python tests/at_size/parity_at_size.py 4096 > gpurun_out/r04/parity_4096.json
+       python tests/at_size/parity_at_size.py 16384 kmeans-only > ...   D alone, on the raster bench.py times (generated on the device):
        the full benchmark size — 268 M labels, seeds and iteration count of the KMeans kernels against the oracle on the same planes."""
 import json
 import os
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "rs-image-segmentation_amd"), ROOT]
 from oracle import ref_np as O  # noqa: E402
 from rsseg import pipeline as P  # noqa: E402

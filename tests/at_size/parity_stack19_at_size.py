@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The 19-feature stack of config 5 (indices, PC0, their 7x7 context means, GLCM 21/21 contrast / homogeneity, 5x5 morphological
 gradient, 5x5 local std, Sobel magnitude) against the CPU oracle at a size beyond the test suite's, on SURVEY 8d's raster:
-column by column, bit-identical or the largest deviation.  Usage: python profiles/r04_parity_stack19_at_size.py 4096 > out.json"""
+column by column, bit-identical or the largest deviation.  Usage: python tests/at_size/parity_stack19_at_size.py 4096 > out.json"""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "rs-image-segmentation_amd"), ROOT]
 from oracle import ref_np as O  # noqa: E402
 from rsseg import pipeline as P  # noqa: E402
