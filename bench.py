@@ -157,7 +157,7 @@ def pattern_rate_gbs(family):
         if family == "indices_project":   # 28 B/px read over 7 planes + 41 B/px written over 11 (profiles/ubench/streams.hip write_heavy, r04):
             wh = json.load(open(os.path.join(ROOT, "profiles", "r04_streams_write_heavy.json")))   # the best launch shape recorded
             return round(max(v["TBs"] for v in wh.values() if isinstance(v, dict) and "TBs" in v and not v.get("other_mix")) * 1000.0, 1)
-        if family == "resize":            # one float32 plane in, one out, 4 bytes per lane: the best bare plane copy recorded (r04_streams_copy.json)
+        if family in ("resize", "ctxmean", "box"):   # as many float32 bytes out as in: the best bare plane copy recorded (r04_streams_copy.json)
             cp = json.load(open(os.path.join(ROOT, "profiles", "r04_streams_copy.json")))
             return round(max(v["TBs"] for v in cp.values() if isinstance(v, dict)) * 1000.0, 1)
         if family == "select":            # one float32 plane read once: the small-integer pass at its best grid (r04_k1_sweep.json) is the pattern
